@@ -1,0 +1,101 @@
+// duckdb-polr_amd/csrc/polr_device.h -- device-side data layout of the POLAR path (gfx950).
+//
+// Everything the path kernels touch lives in HBM in these shapes:
+//   probe side   : SoA columns exactly as the host hands them over (FLAT vectors), optional
+//                  selection list of the tuples that enter the multiplexer.
+//   build side   : SoA key/payload columns indexed by build row + ONE index over the key:
+//       KIND_PERFECT : bit map over [min, max] (1 bit per key value, L2 resident: <= 125 KB) and
+//                      payload columns re-ordered by (key - min), as the reference's perfect table.
+//       KIND_S8      : open addressing, 8-byte slots {key32, row}; unique 32-bit keys (FK -> PK).
+//       KIND_S16     : open addressing, 16-byte slots {key64, start, count}; `rowids[start..+count)`
+//                      holds the rows of that key contiguously (bucket-contiguous runs instead of
+//                      the reference's pointer chains).
+//     load factor <= 0.5, linear probing, so a lookup touches one 64-byte line in the common case.
+//   intermediates: never in HBM.  Tuples between joins live in per-wave LDS queues as row-id
+//                  tuples (late materialisation); only final tuples are written, as row ids.
+#pragma once
+
+#include <stdint.h>
+
+#define POLR_KMAX 8
+#define POLR_PMAX 32
+#define POLR_WMAX (1 + POLR_KMAX)
+
+enum { KIND_NONE = 0, KIND_PERFECT = 1, KIND_S8 = 2, KIND_S16 = 3 };
+
+#define S8_EMPTY_ROW 0xFFFFFFFFu
+#define S16_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+struct DevCol {
+	const uint8_t *data;
+	const uint8_t *valid; // nullptr = all valid
+	uint32_t width;
+	uint32_t flags; // bit0 signed
+};
+
+struct DevJoin {
+	uint32_t kind;
+	uint32_t n_keys;
+	uint32_t key_width[2];
+	uint32_t key_signed;
+	int32_t key_src_join[2];
+	int32_t key_src_col[2];
+	uint32_t n_payload;
+	uint64_t mask;         // hash: capacity - 1
+	int64_t min_value;     // perfect
+	uint64_t range;        // perfect: max - min
+	const void *table;     // S8: uint2[capacity]; S16: uint4[capacity]; perfect: uint32 bit words
+	const uint32_t *rowids; // S16: runs of build rows; perfect: nullptr
+	uint32_t sentinel_start; // S16 side entry for key == S16_EMPTY_KEY
+	uint32_t sentinel_count;
+	const DevCol *payload; // n_payload columns, indexed by build id (perfect: by key - min)
+};
+
+struct DevPath {
+	uint32_t order[POLR_KMAX];
+};
+
+struct DevPipeline {
+	uint32_t k;
+	uint32_t n_paths;
+	uint32_t n_probe_cols;
+	uint32_t W;             // slots carried per tuple: 1 (probe row) + carried build ids
+	uint32_t materialize;   // 1: all build ids carried, slot 1+j = join j
+	int32_t slot_of_join[POLR_KMAX]; // slot index holding join j's build id, or -1
+	const DevCol *probe_cols;
+	const uint32_t *sel;    // nullptr = identity
+	uint64_t n_tuples;
+	DevJoin joins[POLR_KMAX];
+	DevPath paths[POLR_PMAX];
+};
+
+// one routed slice; must match polr_round in include/polr_hip.h
+struct DevRound {
+	uint64_t begin;
+	uint64_t count;
+	uint32_t path;
+	uint32_t emit;
+};
+
+// chunked output (a DataChunk stream of row ids)
+struct DevOut {
+	uint32_t *ids;          // [W_out][max_chunks * chunk_capacity]
+	uint32_t *chunk_count;  // [max_chunks]
+	uint32_t *cursor;       // [0] = next free chunk, [1] = overflow flag
+	uint64_t slot_stride;   // max_chunks * chunk_capacity
+	uint32_t chunk_capacity;
+	uint32_t max_chunks;
+	uint32_t W_out;
+	uint32_t pad;
+};
+
+__host__ __device__ inline uint64_t polr_murmurhash64(uint64_t x) {
+	// same finaliser as the reference (src/include/duckdb/common/types/hash.hpp:22-29); the device
+	// table is re-bucketed so any hash would do, keeping this one keeps bucket statistics comparable
+	x ^= x >> 32;
+	x *= 0xd6e8feb86659fd93ULL;
+	x ^= x >> 32;
+	x *= 0xd6e8feb86659fd93ULL;
+	x ^= x >> 32;
+	return x;
+}

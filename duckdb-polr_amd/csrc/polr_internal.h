@@ -1,0 +1,134 @@
+// duckdb-polr_amd/csrc/polr_internal.h -- host-side objects behind the opaque handles of
+// include/polr_hip.h, shared by polr_capi.hip and polr_mpx.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/polr_hip.h"
+#include "polr_device.h"
+
+struct polr_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int n_cus = 256;
+	std::string err;
+};
+
+struct OwnedCol {
+	uint8_t *data = nullptr;
+	uint8_t *valid = nullptr;
+	uint32_t width = 0;
+	uint32_t flags = 0;
+	bool owned = true;
+};
+
+struct polr_ht {
+	polr_ctx *ctx = nullptr;
+	uint32_t n_keys = 0, n_payload = 0;
+	uint64_t n_rows_in = 0; // rows as uploaded (build row ids index these)
+	uint64_t n_rows = 0;    // rows kept (NULL keys dropped)
+	std::vector<OwnedCol> keys, payload;
+	DevCol *keys_dev = nullptr;    // device array [n_keys]
+	DevCol *payload_dev = nullptr; // device array [n_payload] the probe kernel reads (by build id)
+	uint32_t kind = KIND_NONE;
+	uint32_t key_signed = 0;
+	// hash
+	void *table = nullptr;
+	uint64_t capacity = 0;
+	uint32_t *rowids = nullptr;
+	uint32_t sentinel_start = 0, sentinel_count = 0;
+	uint64_t max_run = 0;
+	// perfect
+	int64_t min_value = 0, max_value = 0;
+	uint64_t range = 0;
+	uint32_t *bits = nullptr;
+	uint32_t *idx_row = nullptr;
+	std::vector<OwnedCol> pcols;
+	uint32_t is_dense = 0, has_null = 0;
+	uint64_t device_bytes = 0;
+};
+
+struct polr_pipeline {
+	polr_ctx *ctx = nullptr;
+	uint32_t k = 0, n_paths = 0, n_probe_cols = 0;
+	uint64_t n_probe_rows = 0;
+	uint64_t n_tuples = 0;
+	std::vector<OwnedCol> probe_cols;
+	DevCol *probe_cols_dev = nullptr;
+	uint32_t *sel_dev = nullptr;
+	bool sel_owned = false;
+	std::vector<polr_ht *> hts;
+	DevPipeline host_count, host_mat; // count-only (narrow tuples) and materialising (all ids) variants
+	DevPipeline *dev_count = nullptr, *dev_mat = nullptr;
+	// launch scratch (grown on demand)
+	DevRound *rounds_dev = nullptr;
+	uint64_t *prefix_dev = nullptr;
+	uint32_t rounds_cap = 0;
+	unsigned long long *counts_dev = nullptr;
+	uint64_t counts_cap = 0;
+};
+
+struct polr_out {
+	polr_pipeline *pipe = nullptr;
+	DevOut dev;
+	uint64_t *chunk_base = nullptr; // [max_chunks] exclusive prefix, refreshed by stats
+	uint64_t *total_dev = nullptr;
+	uint64_t n_rows = 0;
+	uint32_t n_chunks = 0;
+	bool stats_valid = false;
+};
+
+#define POLR_FAIL(ctx_, code_, ...)                                                                                    \
+	do {                                                                                                               \
+		char buf_[512];                                                                                                \
+		snprintf(buf_, sizeof(buf_), __VA_ARGS__);                                                                     \
+		(ctx_)->err = buf_;                                                                                            \
+		return (code_);                                                                                                \
+	} while (0)
+
+#define HIPCHK(ctx_, call_)                                                                                            \
+	do {                                                                                                               \
+		hipError_t e_ = (call_);                                                                                       \
+		if (e_ != hipSuccess) {                                                                                        \
+			POLR_FAIL(ctx_, POLR_E_HIP, "%s failed: %s (%s:%d)", #call_, hipGetErrorString(e_), __FILE__, __LINE__);   \
+		}                                                                                                              \
+	} while (0)
+
+static inline hipStream_t polr_stream(polr_ctx *ctx, void *stream) {
+	return stream ? (hipStream_t)stream : ctx->stream;
+}
+
+// kernels / launchers implemented in polr_build.hip and polr_probe.hip
+size_t polr_path_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_per_block);
+hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
+                                   hipStream_t stream, const DevPipeline *pipe, const DevRound *rounds,
+                                   const uint64_t *unit_prefix, uint32_t n_rounds, uint32_t unit_size, DevOut out,
+                                   unsigned long long *counts);
+void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
+                        DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
+void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,
+                             uint32_t *dst);
+void polr_launch_deserialize_col(hipStream_t st, const uint8_t *rows, uint64_t n_rows, uint32_t row_width, uint32_t col,
+                                 uint32_t offset, uint32_t width, uint8_t *dst, uint8_t *dst_valid);
+void polr_launch_s16_build(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows, uint4 *slots,
+                           uint64_t capacity, uint32_t *slot_of_row, uint32_t *cursor, uint32_t *rowids,
+                           uint32_t *block_sums, uint32_t *scalars, unsigned long long *n_valid);
+void polr_launch_s16_scatter(hipStream_t st, uint64_t n_rows, const uint4 *slots, const uint32_t *slot_of_row,
+                             uint32_t *cursor, uint32_t *rowids, uint32_t sentinel_start, uint32_t *sentinel_cursor);
+void polr_launch_s16_to_s8(hipStream_t st, const uint4 *slots, uint64_t capacity, const uint32_t *rowids, uint2 *s8);
+void polr_launch_pht_mark(hipStream_t st, const DevCol *keys_dev, uint64_t n_rows, int64_t min_value, uint64_t range,
+                          uint32_t is_signed, uint32_t *bits, uint32_t *idx_row, uint32_t *flags,
+                          unsigned long long *unique_keys);
+void polr_launch_pht_gather(hipStream_t st, const uint32_t *bits, const uint32_t *idx_row, uint64_t size, DevCol src,
+                            uint8_t *dst, uint8_t *dst_valid);
+void polr_launch_pack_bitmap(hipStream_t st, const uint8_t *bytes, uint64_t size, uint32_t *bits);
+void polr_launch_chunk_prefix(hipStream_t st, const uint32_t *chunk_count, uint32_t n_chunks, uint64_t *chunk_base,
+                              uint64_t *total);
+
+// shared between capi and mpx
+int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, uint32_t *unit_size,
+                     uint32_t *n_blocks_max);

@@ -1,0 +1,444 @@
+"""ctypes binding of include/polr_hip.h (libpolr_hip.so).
+
+This is the only way Python code (tests, bench.py) reaches the device path: straight through the C
+ABI.  There is no fallback: if the shared library is missing or no gfx950 device is visible every
+entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_PKG))  # duckdb-polr_amd/
+LIB_PATH = os.path.join(_ROOT, "libpolr_hip.so")
+
+MAX_JOINS, MAX_PATHS, MAX_KEYS = 8, 32, 2
+COL_SIGNED, COL_DEVICE = 1, 2
+
+OK, E_NO_DEVICE, E_INVALID, E_UNSUPPORTED, E_HIP, E_DUPLICATE, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6
+
+ROUTING = {"alternate": 0, "adaptive_reinit": 1, "dynamic": 2, "init_once": 3, "opportunistic": 4,
+           "default_path": 5, "backpressure": 6, "exponential_backoff": 7}
+
+EXPORTS = [
+    "polr_abi_version", "polr_ctx_create", "polr_ctx_destroy", "polr_last_error", "polr_ctx_sync",
+    "polr_ht_upload_rows", "polr_ht_upload_columns", "polr_ht_finalize_hash", "polr_ht_finalize_perfect",
+    "polr_pht_upload", "polr_ht_destroy", "polr_ht_get_info", "polr_ht_export", "polr_ht_alloc_like",
+    "polr_pipeline_create", "polr_pipeline_set_selection", "polr_pipeline_destroy",
+    "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
+    "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
+    "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
+    "polr_mpx_destroy",
+]
+
+
+class PolrError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("polr error %d: %s" % (code, text))
+        self.code = code
+
+
+class Col(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("valid", C.c_void_p), ("width", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class JoinDesc(C.Structure):
+    _fields_ = [("ht", C.c_void_p), ("n_keys", C.c_uint32), ("key_src_join", C.c_int32 * MAX_KEYS),
+                ("key_src_col", C.c_int32 * MAX_KEYS)]
+
+
+class Round(C.Structure):
+    _fields_ = [("begin", C.c_uint64), ("count", C.c_uint64), ("path", C.c_uint32), ("emit", C.c_uint32)]
+
+
+class HtInfo(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("n_keys", C.c_uint32), ("n_rows", C.c_uint64), ("capacity", C.c_uint64),
+                ("max_run", C.c_uint64), ("device_bytes", C.c_uint64), ("is_dense", C.c_uint32),
+                ("has_null", C.c_uint32)]
+
+
+class MpxConfig(C.Structure):
+    _fields_ = [("routing", C.c_uint32), ("chunk_size", C.c_uint32), ("regret_budget", C.c_double),
+                ("init_tuple_count", C.c_uint64), ("atc_multiplier", C.c_uint64), ("log_rounds", C.c_uint32),
+                ("max_log_rounds", C.c_uint32)]
+
+
+class MpxStats(C.Structure):
+    _fields_ = [("num_tuples_processed", C.c_uint64), ("num_intermediates", C.c_uint64), ("num_rounds", C.c_uint64),
+                ("input_tuple_count_per_path", C.c_uint64 * MAX_PATHS), ("path_resistances", C.c_double * MAX_PATHS)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libpolr_hip.so and declare prototypes; raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PolrError(E_NO_DEVICE, "libpolr_hip.so not built (run __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64
+    P = C.POINTER
+    L.polr_abi_version.restype = C.c_int
+    L.polr_ctx_create.argtypes = [C.c_int, P(vp)]
+    L.polr_ctx_destroy.argtypes = [vp]
+    L.polr_ctx_destroy.restype = None
+    L.polr_last_error.argtypes = [vp]
+    L.polr_last_error.restype = C.c_char_p
+    L.polr_ctx_sync.argtypes = [vp, vp]
+    L.polr_ht_upload_rows.argtypes = [vp, vp, u64, u32, vp, vp, vp, u32, u32, P(vp)]
+    L.polr_ht_upload_columns.argtypes = [vp, P(Col), u32, P(Col), u32, u64, P(vp)]
+    L.polr_ht_finalize_hash.argtypes = [vp, vp]
+    L.polr_ht_finalize_perfect.argtypes = [vp, i64, i64, vp]
+    L.polr_pht_upload.argtypes = [vp, u32, u32, i64, i64, vp, P(Col), u32, P(vp)]
+    L.polr_ht_destroy.argtypes = [vp]
+    L.polr_ht_destroy.restype = None
+    L.polr_ht_get_info.argtypes = [vp, P(HtInfo)]
+    L.polr_ht_export.argtypes = [vp, vp, P(u64), P(vp), P(u64), P(u32)]
+    L.polr_ht_alloc_like.argtypes = [vp, vp, u64, P(vp)]
+    L.polr_pipeline_create.argtypes = [vp, P(Col), u32, u64, P(JoinDesc), u32, vp, u32, P(vp)]
+    L.polr_pipeline_set_selection.argtypes = [vp, vp, u64, u32]
+    L.polr_pipeline_destroy.argtypes = [vp]
+    L.polr_pipeline_destroy.restype = None
+    L.polr_out_create.argtypes = [vp, u32, u64, P(vp)]
+    L.polr_out_reset.argtypes = [vp, vp]
+    L.polr_out_stats.argtypes = [vp, vp, P(u64), P(u64), P(u32)]
+    L.polr_out_fetch_ids.argtypes = [vp, vp, vp, u64]
+    L.polr_out_materialize.argtypes = [vp, vp, i32, u32, vp, vp, u64, u32]
+    L.polr_out_destroy.argtypes = [vp]
+    L.polr_out_destroy.restype = None
+    L.polr_probe_rounds.argtypes = [vp, vp, P(Round), u32, vp, vp]
+    L.polr_probe_rounds_async.argtypes = [vp, vp, P(Round), u32, vp, vp]
+    L.polr_mpx_create.argtypes = [vp, P(MpxConfig), P(vp)]
+    L.polr_mpx_run.argtypes = [vp, vp, u64, u64, vp]
+    L.polr_mpx_set_chunk_offsets.argtypes = [vp, vp, u64]
+    L.polr_mpx_finish.argtypes = [vp, vp, P(MpxStats)]
+    L.polr_mpx_fetch_log.argtypes = [vp, vp, vp, vp, vp, u64, P(u64)]
+    L.polr_mpx_destroy.argtypes = [vp]
+    L.polr_mpx_destroy.restype = None
+    _lib = L
+    return L
+
+
+def _np_col(arr, valid=None):
+    arr = np.ascontiguousarray(arr)
+    width = arr.dtype.itemsize
+    flags = COL_SIGNED if arr.dtype.kind == "i" else 0
+    c = Col(arr.ctypes.data, None, width, flags)
+    c._keep = [arr]
+    if valid is not None:
+        valid = np.ascontiguousarray(valid, dtype=np.uint8)
+        c.valid = valid.ctypes.data
+        c._keep.append(valid)
+    return c
+
+
+def dev_col(ptr, width, signed=False, valid_ptr=None):
+    """column descriptor for memory that is already on the device (e.g. a torch tensor's data_ptr())"""
+    return Col(ptr, valid_ptr, width, COL_DEVICE | (COL_SIGNED if signed else 0))
+
+
+def _col_array(cols):
+    arr = (Col * max(len(cols), 1))(*cols)
+    arr._keep = cols
+    return arr
+
+
+class Context:
+    def __init__(self, device_id=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.polr_ctx_create(device_id, C.byref(h))
+        if rc != OK:
+            raise PolrError(rc, "polr_ctx_create(%d) failed: no gfx950 device visible" % device_id)
+        self.h = h
+
+    def check(self, rc):
+        if rc != OK:
+            raise PolrError(rc, self.L.polr_last_error(self.h).decode())
+
+    def sync(self, stream=None):
+        self.check(self.L.polr_ctx_sync(self.h, stream))
+
+    def close(self):
+        if self.h:
+            self.L.polr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HashTable:
+    """A build side resident in HBM."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    @classmethod
+    def from_columns(cls, ctx, keys, payload=(), key_valid=None, payload_valid=None):
+        """keys/payload: numpy arrays or pre-built Col descriptors (device memory)"""
+        kv = key_valid or [None] * len(keys)
+        pv = payload_valid or [None] * len(payload)
+        kc = [k if isinstance(k, Col) else _np_col(k, v) for k, v in zip(keys, kv)]
+        pc = [p if isinstance(p, Col) else _np_col(p, v) for p, v in zip(payload, pv)]
+        n = len(keys[0]) if not isinstance(keys[0], Col) else None
+        return cls.from_cols(ctx, kc, pc, n)
+
+    @classmethod
+    def from_cols(cls, ctx, key_cols, payload_cols, n_rows):
+        h = C.c_void_p()
+        ctx.check(ctx.L.polr_ht_upload_columns(ctx.h, _col_array(key_cols), len(key_cols), _col_array(payload_cols),
+                                               len(payload_cols), n_rows, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_rows(cls, ctx, rows, n_rows, row_width, col_offset, col_width, col_signed, n_keys, n_payload):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        off = np.ascontiguousarray(col_offset, dtype=np.uint32)
+        wid = np.ascontiguousarray(col_width, dtype=np.uint32)
+        flg = np.ascontiguousarray([COL_SIGNED if s else 0 for s in col_signed], dtype=np.uint32)
+        h = C.c_void_p()
+        ctx.check(ctx.L.polr_ht_upload_rows(ctx.h, rows.ctypes.data, n_rows, row_width, off.ctypes.data,
+                                            wid.ctypes.data, flg.ctypes.data, n_keys, n_payload, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_perfect(cls, ctx, key_width, key_signed, min_value, max_value, bitmap, payload=(), payload_valid=None):
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        pv = payload_valid or [None] * len(payload)
+        pc = [_np_col(p, v) for p, v in zip(payload, pv)]
+        h = C.c_void_p()
+        ctx.check(ctx.L.polr_pht_upload(ctx.h, key_width, COL_SIGNED if key_signed else 0, int(min_value),
+                                        int(max_value), bitmap.ctypes.data, _col_array(pc), len(pc), C.byref(h)))
+        return cls(ctx, h)
+
+    def finalize_hash(self, stream=None):
+        self.ctx.check(self.ctx.L.polr_ht_finalize_hash(self.h, stream))
+        return self
+
+    def finalize_perfect(self, min_value, max_value, stream=None):
+        """returns False on a duplicate key (caller falls back to finalize_hash)"""
+        rc = self.ctx.L.polr_ht_finalize_perfect(self.h, int(min_value), int(max_value), stream)
+        if rc == E_DUPLICATE:
+            return False
+        self.ctx.check(rc)
+        return True
+
+    def info(self):
+        i = HtInfo()
+        self.ctx.check(self.ctx.L.polr_ht_get_info(self.h, C.byref(i)))
+        return {f[0]: getattr(i, f[0]) for f in HtInfo._fields_}
+
+    def export(self):
+        """(meta bytes, [(device ptr, nbytes)]) of the finalized table, for a broadcast"""
+        L = self.ctx.L
+        mb, nb = C.c_uint64(0), C.c_uint32(0)
+        self.ctx.check(L.polr_ht_export(self.h, None, C.byref(mb), None, None, C.byref(nb)))
+        meta = (C.c_uint8 * mb.value)()
+        ptrs = (C.c_void_p * nb.value)()
+        sizes = (C.c_uint64 * nb.value)()
+        self.ctx.check(L.polr_ht_export(self.h, meta, C.byref(mb), ptrs, sizes, C.byref(nb)))
+        return bytes(meta), [(ptrs[i], sizes[i]) for i in range(nb.value)]
+
+    @classmethod
+    def alloc_like(cls, ctx, meta):
+        buf = (C.c_uint8 * len(meta)).from_buffer_copy(meta)
+        h = C.c_void_p()
+        ctx.check(ctx.L.polr_ht_alloc_like(ctx.h, buf, len(meta), C.byref(h)))
+        return cls(ctx, h)
+
+    def close(self):
+        if self.h:
+            self.ctx.L.polr_ht_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pipeline:
+    def __init__(self, ctx, probe_cols, n_probe_rows, joins, paths, probe_valid=None):
+        """probe_cols: numpy arrays or Col descriptors; joins: [(HashTable, [(src_join, src_col)])]"""
+        self.ctx = ctx
+        pv = probe_valid or [None] * len(probe_cols)
+        pc = [c if isinstance(c, Col) else _np_col(c, v) for c, v in zip(probe_cols, pv)]
+        self.k = len(joins)
+        jd = (JoinDesc * self.k)()
+        self._hts = [j[0] for j in joins]
+        for i, (ht, key_src) in enumerate(joins):
+            jd[i].ht = ht.h
+            jd[i].n_keys = len(key_src)
+            for c, (sj, sc) in enumerate(key_src):
+                jd[i].key_src_join[c] = sj
+                jd[i].key_src_col[c] = sc
+        paths = np.ascontiguousarray(np.asarray(paths, dtype=np.int32).reshape(-1, self.k))
+        self.n_paths = len(paths)
+        h = C.c_void_p()
+        ctx.check(ctx.L.polr_pipeline_create(ctx.h, _col_array(pc), len(pc), n_probe_rows, jd, self.k,
+                                             paths.ctypes.data, self.n_paths, C.byref(h)))
+        self.h = h
+
+    def set_selection(self, sel, device=False, n=None):
+        if sel is None:
+            self.ctx.check(self.ctx.L.polr_pipeline_set_selection(self.h, None, 0, 0))
+        elif device:
+            self.ctx.check(self.ctx.L.polr_pipeline_set_selection(self.h, sel, n, COL_DEVICE))
+        else:
+            sel = np.ascontiguousarray(sel, dtype=np.uint32)
+            self.ctx.check(self.ctx.L.polr_pipeline_set_selection(self.h, sel.ctypes.data, len(sel), 0))
+
+    def probe_rounds(self, rounds, out=None, stream=None):
+        """rounds: [(begin, count, path, emit)] -> counts ndarray [n_rounds, k]"""
+        n = len(rounds)
+        arr = (Round * n)()
+        for i, (b, c, p, e) in enumerate(rounds):
+            arr[i].begin, arr[i].count, arr[i].path, arr[i].emit = int(b), int(c), int(p), int(e)
+        counts = np.zeros((n, self.k), dtype=np.uint64)
+        rc = self.ctx.L.polr_probe_rounds(self.h, stream, arr, n, out.h if out else None, counts.ctypes.data)
+        if rc == E_OVERFLOW:
+            raise PolrError(rc, self.ctx.L.polr_last_error(self.ctx.h).decode())
+        self.ctx.check(rc)
+        return counts
+
+    def probe_rounds_async(self, rounds_struct, n, counts_dev_ptr, out=None, stream=None):
+        self.ctx.check(self.ctx.L.polr_probe_rounds_async(self.h, stream, rounds_struct, n, out.h if out else None,
+                                                          counts_dev_ptr))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.polr_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_rounds(rounds):
+    arr = (Round * len(rounds))()
+    for i, (b, c, p, e) in enumerate(rounds):
+        arr[i].begin, arr[i].count, arr[i].path, arr[i].emit = int(b), int(c), int(p), int(e)
+    return arr
+
+
+class Output:
+    def __init__(self, pipe, chunk_capacity=1024, max_chunks=1024):
+        self.pipe = pipe
+        self.ctx = pipe.ctx
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.L.polr_out_create(pipe.h, chunk_capacity, max_chunks, C.byref(h)))
+        self.h = h
+
+    def reset(self, stream=None):
+        self.ctx.check(self.ctx.L.polr_out_reset(self.h, stream))
+
+    def stats(self, stream=None):
+        n, c, o = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self.ctx.check(self.ctx.L.polr_out_stats(self.h, stream, C.byref(n), C.byref(c), C.byref(o)))
+        return n.value, c.value, bool(o.value)
+
+    def fetch_ids(self, stream=None):
+        n, _, _ = self.stats(stream)
+        out = np.zeros((n, 1 + self.pipe.k), dtype=np.uint32)
+        self.ctx.check(self.ctx.L.polr_out_fetch_ids(self.h, stream, out.ctypes.data, n))
+        return out
+
+    def materialize(self, src_join, src_col, dtype, stream=None):
+        n, _, _ = self.stats(stream)
+        data = np.zeros((n,), dtype=dtype)
+        valid = np.ones((n,), dtype=np.uint8)
+        self.ctx.check(self.ctx.L.polr_out_materialize(self.h, stream, src_join, src_col, data.ctypes.data,
+                                                       valid.ctypes.data, n, 0))
+        return data, valid
+
+    def close(self):
+        if self.h:
+            self.ctx.L.polr_out_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceMultiplexer:
+    def __init__(self, pipe, routing, chunk_size=1024, regret_budget=0.01, init_tuple_count=1024, atc_multiplier=1,
+                 log_rounds=True, max_log_rounds=1 << 20):
+        self.pipe = pipe
+        self.ctx = pipe.ctx
+        cfg = MpxConfig(ROUTING[routing] if isinstance(routing, str) else routing, chunk_size, regret_budget,
+                        init_tuple_count, atc_multiplier, int(log_rounds), max_log_rounds)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.L.polr_mpx_create(pipe.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.max_log_rounds = max_log_rounds
+
+    def set_chunk_offsets(self, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.ctx.check(self.ctx.L.polr_mpx_set_chunk_offsets(self.h, offsets.ctypes.data, len(offsets) - 1))
+
+    def run(self, chunk_begin, chunk_end, out=None, stream=None):
+        self.ctx.check(self.ctx.L.polr_mpx_run(self.h, stream, chunk_begin, chunk_end, out.h if out else None))
+
+    def finish(self, stream=None):
+        st = MpxStats()
+        self.ctx.check(self.ctx.L.polr_mpx_finish(self.h, stream, C.byref(st)))
+        P = self.pipe.n_paths
+        return {"num_tuples_processed": st.num_tuples_processed, "num_intermediates": st.num_intermediates,
+                "num_rounds": st.num_rounds,
+                "input_tuple_count_per_path": [st.input_tuple_count_per_path[i] for i in range(P)],
+                "path_resistances": [st.path_resistances[i] for i in range(P)]}
+
+    def fetch_log(self, stream=None):
+        n = C.c_uint64()
+        cap = self.max_log_rounds
+        path = np.zeros((cap,), dtype=np.uint32)
+        tuples = np.zeros((cap,), dtype=np.uint64)
+        inter = np.zeros((cap,), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.polr_mpx_fetch_log(self.h, stream, path.ctypes.data, tuples.ctypes.data,
+                                                     inter.ctypes.data, cap, C.byref(n)))
+        m = n.value
+        return path[:m].copy(), tuples[:m].copy(), inter[:m].copy()
+
+    def close(self):
+        if self.h:
+            self.ctx.L.polr_mpx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_joins(ctx, wl):
+    """upload + finalize the build sides of a workload dict the way the reference's planner would:
+    perfect table where the plan allows it and the build has no duplicate, hash table otherwise."""
+    joins = []
+    for j in wl["joins"]:
+        pv = [j.get("payload_valid", {}).get(n) for n in j["payload"].keys()]
+        ht = HashTable.from_columns(ctx, j["keys"], list(j["payload"].values()), key_valid=j.get("key_valid"),
+                                    payload_valid=pv)
+        done = False
+        if j.get("perfect") is not None:
+            done = ht.finalize_perfect(*j["perfect"])
+        if not done:
+            ht.finalize_hash()
+        joins.append((ht, j["key_src"]))
+    return joins

@@ -1,0 +1,258 @@
+"""Seeded synthetic workloads shaped like the reference's benchmarks.
+
+The reference loads IMDB/SSB data over the network (benchmark/imdb/init/load.sql:1-21,
+benchmark/ssb/init/load.sql:74-78); neither is available offline, so every configuration runs on
+generated tables with the same schemas, cardinalities and key skew.  All generators are pure
+functions of (name, scale, seed) so that tests, the golden-vector maker and bench.py see the same
+bytes.  seed 1337 = the reference's default ClientConfig::seed (client_config.hpp:81).
+
+A workload is a dict:
+  probe:   {"name", "cols": {col: ndarray}, "key_cols": [...]}
+  joins:   list (original join order = path 0) of
+           {"name", "keys": [ndarray], "payload": {col: ndarray}, "key_src": [(-1|join, col index)],
+            "perfect": (min, max) or None, "sql_type": ...}
+  sql:     how the same query reads for the reference (used only by the golden maker / cpu baseline)
+"""
+import numpy as np
+
+SEED = 1337
+
+
+def _rng(seed, salt):
+    return np.random.default_rng(np.random.SeedSequence([seed, salt]))
+
+
+def zipf_keys(rng, n, n_keys, s=1.0):
+    """n draws from a bounded Zipf(s) over [0, n_keys) (rank 0 most frequent), then the ranks are
+    scattered over the key space with a fixed permutation so hot keys are not the small ids."""
+    ranks = np.arange(1, n_keys + 1, dtype=np.float64)
+    w = ranks ** (-s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    u = rng.random(n)
+    idx = np.searchsorted(cdf, u, side="left").astype(np.int64)
+    perm = rng.permutation(n_keys)
+    return perm[idx]
+
+
+# -------------------------------------------------------------------------------------------------
+# star join with phase skew: the selective dimension changes along the scan order, which is what
+# the SSB-skew transforms do (benchmark/ssb-skew/init/load.sql:80-253, Appendix D of SURVEY.md)
+# -------------------------------------------------------------------------------------------------
+def star_skew(n_fact=200_000, seed=SEED, n_phases=4, dims=((60_000, 37, 0), (2_000, 1, 0), (20_000, 5, 3)),
+              with_nulls=False):
+    """dims: (n_keys, key_stride, max_dup).  key_stride > 1 spreads the key range past the
+    perfect-hash limit when n_keys*stride > 1e6; max_dup > 0 repeats build keys 1..max_dup times."""
+    rng = _rng(seed, 1)
+    joins = []
+    fact = {"id": np.arange(n_fact, dtype=np.int32)}
+    phase = (np.arange(n_fact) * n_phases // n_fact).astype(np.int64)
+    for d, (n_keys, stride, max_dup) in enumerate(dims):
+        keys = (np.arange(n_keys, dtype=np.int64) * stride + 11).astype(np.int32)
+        if max_dup:
+            reps = rng.integers(1, max_dup + 1, size=n_keys)
+            bkeys = np.repeat(keys, reps)
+            bkeys = bkeys[rng.permutation(len(bkeys))]
+        else:
+            bkeys = keys[rng.permutation(n_keys)]
+        # a dimension filter keeps a fraction of the build keys; the fraction of FACT rows that hit a
+        # kept key depends on the phase: dimension d is very selective in phase d, loose elsewhere
+        keep = rng.random(n_keys) < 0.5
+        kept_keys = keys[keep]
+        dropped_keys = keys[~keep]
+        hit_prob = np.where(phase % len(dims) == d, 0.05, 0.9)
+        hit = rng.random(n_fact) < hit_prob
+        fk = np.where(hit, kept_keys[rng.integers(0, len(kept_keys), n_fact)],
+                      dropped_keys[rng.integers(0, len(dropped_keys), n_fact)]).astype(np.int32)
+        fact["k%d" % d] = fk
+        sel = np.isin(bkeys, kept_keys)
+        bkeys = bkeys[sel]
+        payload = {"p%d" % d: (bkeys.astype(np.int64) * 7 + d).astype(np.int32),
+                   "q%d" % d: (bkeys % 251).astype(np.int16)}
+        kmin, kmax = int(keys.min()), int(keys.max())
+        perfect = (kmin, kmax) if (kmax - kmin) <= 1_000_000 and not max_dup else None
+        joins.append({"name": "d%d" % d, "keys": [bkeys.astype(np.int32)], "key_names": ["k"],
+                      "payload": payload, "key_src": [(-1, 1 + d)], "perfect": perfect})
+    wl = {"name": "star_skew", "probe": {"name": "fact", "cols": fact}, "joins": joins}
+    if with_nulls:
+        wl["name"] = "star_skew_nulls"
+        pv = {}
+        for d in range(len(dims)):
+            v = (rng.random(n_fact) > 0.03).astype(np.uint8)
+            pv["k%d" % d] = v
+        wl["probe"]["valid"] = pv
+        for d, j in enumerate(joins):
+            n = len(j["keys"][0])
+            j["key_valid"] = [(rng.random(n) > 0.02).astype(np.uint8)]
+            j["payload_valid"] = {"p%d" % d: (rng.random(n) > 0.1).astype(np.uint8)}
+            j["perfect"] = None if j["perfect"] is None else j["perfect"]
+    return wl
+
+
+# -------------------------------------------------------------------------------------------------
+# dependent chain: join 1 probes with a column that join 0's build side provides
+# (left_expression_bindings, polar_config.cpp:152-229); join 2 is independent
+# -------------------------------------------------------------------------------------------------
+def chain_dep(n_fact=120_000, seed=SEED):
+    rng = _rng(seed, 2)
+    n_a, n_b, n_c = 30_000, 8_000, 5_000
+    a_keys = (np.arange(n_a, dtype=np.int64) * 41 + 5).astype(np.int32)
+    b_keys = (np.arange(n_b, dtype=np.int64) * 3 + 1).astype(np.int32)
+    c_keys = (np.arange(n_c, dtype=np.int32) + 100).astype(np.int32)
+    a_keep = rng.random(n_a) < 0.6
+    a_bref = b_keys[rng.integers(0, n_b, n_a)]          # a.bref -> b.k (FK carried by the build side)
+    a_bref = np.where(rng.random(n_a) < 0.7, a_bref, a_bref + 1).astype(np.int32)  # some miss b
+    fact = {
+        "id": np.arange(n_fact, dtype=np.int32),
+        "ak": a_keys[zipf_keys(rng, n_fact, n_a, 0.8)].astype(np.int32),
+        "ck": np.where(rng.random(n_fact) < 0.4, c_keys[rng.integers(0, n_c, n_fact)], 7).astype(np.int32),
+    }
+    perm = rng.permutation(int(a_keep.sum()))
+    ja = {"name": "a", "keys": [a_keys[a_keep][perm]], "key_names": ["k"],
+          "payload": {"bref": a_bref[a_keep][perm], "av": (a_keys[a_keep][perm] % 1000).astype(np.int32)},
+          "key_src": [(-1, 1)], "perfect": None}
+    jb = {"name": "b", "keys": [b_keys[rng.permutation(n_b)]], "key_names": ["k"],
+          "payload": {"bv": None}, "key_src": [(0, 0)], "perfect": (int(b_keys.min()), int(b_keys.max()))}
+    jb["payload"]["bv"] = (jb["keys"][0].astype(np.int64) * 13 % 9973).astype(np.int32)
+    cdup = np.repeat(c_keys, rng.integers(1, 4, size=n_c))
+    cdup = cdup[rng.permutation(len(cdup))]
+    jc = {"name": "c", "keys": [cdup.astype(np.int32)], "key_names": ["k"],
+          "payload": {"cv": (np.arange(len(cdup)) % 97).astype(np.int16)}, "key_src": [(-1, 2)], "perfect": None}
+    return {"name": "chain_dep", "probe": {"name": "fact", "cols": fact}, "joins": [ja, jb, jc]}
+
+
+# -------------------------------------------------------------------------------------------------
+# heavy fan-out (JOB's cast_info / movie_info style duplicates)
+# -------------------------------------------------------------------------------------------------
+def fanout(n_fact=40_000, seed=SEED):
+    rng = _rng(seed, 3)
+    n_m = 6_000
+    m_keys = (np.arange(n_m, dtype=np.int64) * 211 + 3).astype(np.int32)
+    reps1 = np.minimum(rng.zipf(1.6, size=n_m), 300)
+    b1 = np.repeat(m_keys, reps1)
+    b1 = b1[rng.permutation(len(b1))]
+    reps2 = rng.integers(0, 5, size=n_m)
+    b2 = np.repeat(m_keys, reps2)
+    b2 = b2[rng.permutation(len(b2))]
+    fact = {"id": np.arange(n_fact, dtype=np.int32),
+            "mk": np.where(rng.random(n_fact) < 0.7, m_keys[zipf_keys(rng, n_fact, n_m, 1.0)], 1).astype(np.int32)}
+    j1 = {"name": "ci", "keys": [b1.astype(np.int32)], "key_names": ["movie_id"],
+          "payload": {"role": (np.arange(len(b1)) % 11).astype(np.int32)}, "key_src": [(-1, 1)], "perfect": None}
+    j2 = {"name": "mk", "keys": [b2.astype(np.int32)], "key_names": ["movie_id"],
+          "payload": {"kw": (np.arange(len(b2)) * 3 % 1009).astype(np.int32)}, "key_src": [(-1, 1)], "perfect": None}
+    return {"name": "fanout", "probe": {"name": "fact", "cols": fact}, "joins": [j1, j2]}
+
+
+# -------------------------------------------------------------------------------------------------
+# JOB-light 01 shape (BASELINE.json configs[1]):
+#   SELECT COUNT(*) FROM movie_companies mc, title t, movie_info_idx mi_idx
+#   WHERE t.id=mc.movie_id AND t.id=mi_idx.movie_id AND mi_idx.info_type_id=112 AND mc.company_type_id=2
+# (benchmark/job-light/queries/01.sql).  Probe side = movie_companies (2 609 129 rows) filtered on
+# company_type_id; builds = title (2 528 312 rows, dense ids -> key range > 1e6 -> chained table)
+# and movie_info_idx filtered on info_type_id (1 380 035 rows before the filter).
+# -------------------------------------------------------------------------------------------------
+JOB_CARD = {"title": 2_528_312, "movie_companies": 2_609_129, "movie_info_idx": 1_380_035,
+            "cast_info": 36_244_344, "movie_info": 14_835_720, "movie_keyword": 4_523_930, "name": 4_167_491}
+
+
+def job_light_01(scale=1.0, seed=SEED):
+    rng = _rng(seed, 4)
+    n_t = max(int(JOB_CARD["title"] * scale), 1000)
+    n_mc = max(int(JOB_CARD["movie_companies"] * scale), 1000)
+    n_mi = max(int(JOB_CARD["movie_info_idx"] * scale), 1000)
+    t_id = np.arange(1, n_t + 1, dtype=np.int32)
+    t_id = t_id[rng.permutation(n_t)]
+    mc_movie = (zipf_keys(rng, n_mc, n_t, 1.0) + 1).astype(np.int32)
+    mc_ctype = rng.integers(1, 3, n_mc).astype(np.int32)
+    # movie_info_idx: up to 3 info rows per movie for about a fifth of the movies, types 99..113
+    mi_movie = (zipf_keys(rng, n_mi, n_t, 0.6) + 1).astype(np.int32)
+    mi_type = rng.integers(99, 114, n_mi).astype(np.int32)
+    mc_sel = np.nonzero(mc_ctype == 2)[0].astype(np.uint32)
+    mi_keep = mi_type == 112
+    probe = {"name": "movie_companies", "cols": {"movie_id": mc_movie, "company_type_id": mc_ctype},
+             "filter_sel": mc_sel, "filter_sql": "company_type_id=2"}
+    jt = {"name": "title", "keys": [t_id], "key_names": ["id"], "payload": {}, "key_src": [(-1, 0)], "perfect": None}
+    jmi = {"name": "movie_info_idx", "keys": [mi_movie[mi_keep]], "key_names": ["movie_id"], "payload": {},
+           "key_src": [(-1, 0)], "perfect": None,
+           "unfiltered": {"movie_id": mi_movie, "info_type_id": mi_type}, "filter_sql": "info_type_id=112"}
+    return {"name": "job_light_01", "probe": probe, "joins": [jt, jmi]}
+
+
+# -------------------------------------------------------------------------------------------------
+# SSB-skew Q4.1 shape (BASELINE.json configs[2]): lineorder x {customer, supplier, part, date}
+# with the selective dimension changing along lo_orderkey (benchmark/ssb-skew/init/load.sql:80-253,
+# queries/q4-1.sql).  scale=1.0 is SF100 (600 M lineorder rows); the dimension cardinalities follow
+# the SSB specification (customer 30k*SF, supplier 2k*SF, part 200k*(1+log2 SF), date 2556).
+# -------------------------------------------------------------------------------------------------
+def ssb_skew_q41(sf=1.0, seed=SEED, n_lineorder=None):
+    rng = _rng(seed, 5)
+    n_lo = int(6_000_000 * sf) if n_lineorder is None else int(n_lineorder)
+    n_c = max(int(30_000 * sf), 3000)
+    n_s = max(int(2_000 * sf), 200)
+    n_p = max(int(200_000 * (1 + np.log2(max(sf, 1)))), 20_000)
+    n_d = 2556
+    regions = 5
+    c_region = rng.integers(0, regions, n_c)
+    # skew: 90% of non-AMERICA(=1) customers rewritten to AMERICA (load.sql:81-82)
+    c_region = np.where((c_region != 1) & (rng.random(n_c) < 0.9), 1, c_region)
+    s_region = rng.integers(0, regions, n_s)
+    s_region = np.where(rng.random(n_s) < 0.9, 2, s_region)  # 90% -> ASIA (load.sql:139-140)
+    p_mfgr = rng.integers(1, 6, n_p)
+    d_keys = (19920101 + np.arange(n_d)).astype(np.uint32)
+    d_year = (1992 + np.arange(n_d) * 7 // n_d).astype(np.uint16)
+    pos = np.arange(n_lo)
+    band = pos * 7 // n_lo  # lo_orderdate is a function of the orderkey band (load.sql:190-245)
+    lo_date = d_keys[(band * (n_d // 7) + rng.integers(0, n_d // 7, n_lo)).clip(0, n_d - 1)]
+    lo_cust = rng.integers(1, n_c + 1, n_lo).astype(np.uint32)
+    lo_supp = rng.integers(1, n_s + 1, n_lo).astype(np.uint32)
+    lo_part = rng.integers(1, n_p + 1, n_lo).astype(np.uint32)
+    # re-point keys by scan position (load.sql:102-132,146-178): first 2/3 of the scan avoids the
+    # AMERICA customers, the last third avoids the AMERICA suppliers
+    am_c = np.nonzero(c_region == 1)[0].astype(np.uint32) + 1
+    non_am_c = np.nonzero(c_region != 1)[0].astype(np.uint32) + 1
+    am_s = np.nonzero(s_region == 1)[0].astype(np.uint32) + 1
+    non_am_s = np.nonzero(s_region != 1)[0].astype(np.uint32) + 1
+    early = pos < (2 * n_lo) // 3
+    if len(non_am_c) and len(am_c):
+        lo_cust = np.where(early & (rng.random(n_lo) < 0.85), non_am_c[rng.integers(0, len(non_am_c), n_lo)], lo_cust)
+        lo_cust = np.where(~early, am_c[rng.integers(0, len(am_c), n_lo)], lo_cust)
+    if len(non_am_s) and len(am_s):
+        lo_supp = np.where(early, am_s[rng.integers(0, len(am_s), n_lo)], lo_supp)
+        lo_supp = np.where(~early & (rng.random(n_lo) < 0.9), non_am_s[rng.integers(0, len(non_am_s), n_lo)], lo_supp)
+    lineorder = {"lo_custkey": lo_cust.astype(np.uint32), "lo_suppkey": lo_supp.astype(np.uint32),
+                 "lo_partkey": lo_part.astype(np.uint32), "lo_orderdate": lo_date.astype(np.uint32),
+                 "lo_revenue": rng.integers(100, 10_000, n_lo).astype(np.uint32),
+                 "lo_supplycost": rng.integers(50, 5_000, n_lo).astype(np.uint32)}
+    c_keep = c_region == 1
+    s_keep = s_region == 1
+    p_keep = (p_mfgr == 1) | (p_mfgr == 2)
+    c_keys = (np.nonzero(c_keep)[0] + 1).astype(np.uint32)
+    s_keys = (np.nonzero(s_keep)[0] + 1).astype(np.uint32)
+    p_keys = (np.nonzero(p_keep)[0] + 1).astype(np.uint32)
+
+    def perfect(n):
+        return (1, n) if n - 1 <= 1_000_000 else None
+
+    jc = {"name": "customer", "keys": [c_keys], "key_names": ["c_custkey"],
+          "payload": {"c_nation": (c_keys % 25).astype(np.uint16)}, "key_src": [(-1, 0)], "perfect": perfect(n_c)}
+    js = {"name": "supplier", "keys": [s_keys], "key_names": ["s_suppkey"], "payload": {}, "key_src": [(-1, 1)],
+          "perfect": perfect(n_s)}
+    jp = {"name": "part", "keys": [p_keys], "key_names": ["p_partkey"], "payload": {}, "key_src": [(-1, 2)],
+          "perfect": perfect(n_p)}
+    jd = {"name": "date", "keys": [d_keys], "key_names": ["d_datekey"], "payload": {"d_year": d_year},
+          "key_src": [(-1, 3)], "perfect": (int(d_keys.min()), int(d_keys.max()))}
+    return {"name": "ssb_skew_q41", "probe": {"name": "lineorder", "cols": lineorder}, "joins": [jc, js, jp, jd]}
+
+
+def default_paths(k, kind="each_last_once"):
+    """Join orders a deterministic enumerator of the reference yields when no join depends on
+    another (EachLastOnceEnumeration / EachFirstOnceEnumeration, polar_enumeration_algo.cpp:610-667)."""
+    base = list(range(k))
+    paths = [base]
+    if kind == "each_last_once":
+        for i in range(k - 1):
+            paths.append([j for j in base if j != i] + [i])
+    elif kind == "each_first_once":
+        for i in range(1, k):
+            paths.append([i] + [j for j in base if j != i])
+    return np.asarray(paths, dtype=np.int32)

@@ -1,0 +1,239 @@
+/*
+ * include/polr_hip.h -- the drop-in boundary of the MI355X POLAR path.
+ *
+ * A thin C ABI (plain pointers and sizes, no C++/torch types) under the reference's operator
+ * classes.  The reference (d-justen/duckdb-polr) has no FFI seam: PhysicalMultiplexer,
+ * PhysicalHashJoin and PhysicalAdaptiveUnion are C++ classes linked into libduckdb, and the
+ * boundary sits inside POLARPipelineExecutor::RunPath (src/parallel/polar_pipeline_executor.cpp:
+ * 427-538).  Each entry point below names the reference code whose job it takes over; the
+ * C++ host mirror in duckdb-polr_amd/host/ (same class names as the reference) is the only
+ * intended caller, INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: every call returns 0 on success or a negative POLR_E_* code; polr_last_error()
+ * returns the text of the last failure of that context (thread-compatible: one context per host
+ * thread, like one PipelineExecutor per thread in the reference).  The caller owns host buffers;
+ * the library owns device buffers behind opaque handles.  `stream` is a hipStream_t passed as
+ * void* (NULL = the context's own stream).  There is NO CPU fallback: without a visible gfx950
+ * device polr_ctx_create fails with POLR_E_NO_DEVICE.
+ */
+#ifndef POLR_HIP_H
+#define POLR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLR_ABI_VERSION 1
+
+#define POLR_MAX_JOINS 8   /* consecutive INNER hash joins multiplexed in one pipeline */
+#define POLR_MAX_PATHS 32  /* >= max_join_orders used by the reference's experiments (24) */
+#define POLR_MAX_KEYS 2    /* equality conditions per join (composite keys up to 2 x 32 bit) */
+
+enum {
+	POLR_OK = 0,
+	POLR_E_NO_DEVICE = -1,
+	POLR_E_INVALID = -2,     /* bad argument / shape mismatch (checked on the host before any launch) */
+	POLR_E_UNSUPPORTED = -3, /* type or plan shape outside the path (fails loudly, never falls back) */
+	POLR_E_HIP = -4,         /* a HIP runtime call failed; text in polr_last_error */
+	POLR_E_DUPLICATE = -5,   /* perfect-hash build saw a duplicate key: caller keeps the chained table,
+	                            like perfect_hash_join_executor.cpp:112-114 */
+	POLR_E_OVERFLOW = -6     /* output buffer too small; counters are still exact */
+};
+
+/* MultiplexerRouting (src/include/duckdb/main/config.hpp:41-50), same order */
+enum {
+	POLR_ROUTE_ALTERNATE = 0,
+	POLR_ROUTE_ADAPTIVE_REINIT = 1,
+	POLR_ROUTE_DYNAMIC = 2,
+	POLR_ROUTE_INIT_ONCE = 3,
+	POLR_ROUTE_OPPORTUNISTIC = 4,
+	POLR_ROUTE_DEFAULT_PATH = 5,
+	POLR_ROUTE_BACKPRESSURE = 6,
+	POLR_ROUTE_EXPONENTIAL_BACKOFF = 7
+};
+
+typedef struct polr_ctx polr_ctx;           /* one device + one stream + error text */
+typedef struct polr_ht polr_ht;             /* a finalized build side resident in HBM */
+typedef struct polr_pipeline polr_pipeline; /* probe columns + joins + join orders (POLARConfig) */
+typedef struct polr_out polr_out;           /* chunked output of a run (DataChunk stream) */
+typedef struct polr_mpx polr_mpx;           /* device-resident multiplexer state + router */
+
+/* A flat column (FLAT vector after ToUnifiedFormat, src/include/duckdb/common/types/vector.hpp:22-27).
+ * valid: NULL = all valid, else one byte per row (1 = valid).  width in bytes: 1, 2, 4, 8 or 16
+ * (16 = string_t copied as an opaque cell, row_gather.cpp:47-86). */
+#define POLR_COL_SIGNED 1u
+#define POLR_COL_DEVICE 2u /* data/valid are device pointers (e.g. torch tensors) */
+typedef struct polr_col {
+	const void *data;
+	const uint8_t *valid;
+	uint32_t width;
+	uint32_t flags;
+} polr_col;
+
+/* ---------------------------------------------------------------------------------------------
+ * Context
+ * ------------------------------------------------------------------------------------------- */
+int polr_abi_version(void);
+int polr_ctx_create(int device_id, polr_ctx **out);
+void polr_ctx_destroy(polr_ctx *ctx);
+const char *polr_last_error(const polr_ctx *ctx);
+int polr_ctx_sync(polr_ctx *ctx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Build sides.  Replaces what JoinHashTable::Finalize leaves in host memory
+ * (src/execution/join_hashtable.cpp:324-377) with a device-native layout:
+ *   - keys/payload de-serialised into SoA columns indexed by build row,
+ *   - an open-addressing bucket array: 8-byte {key,row} slots for a unique 32-bit key, 16-byte
+ *     {key64,start,count} slots + a row-id run array when the key repeats (bucket-contiguous
+ *     instead of pointer-chained: the reference's chain order is not part of its contract,
+ *     join_hashtable.cpp:284-303),
+ *   - or the direct-address perfect table of perfect_hash_join_executor.cpp:20-122.
+ * Build row ids reported anywhere in this API are the ordinals of the rows as uploaded.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Upload the reference's row-format blob (RowLayout, src/common/types/row_layout.cpp:19-80;
+ * JoinHashTable ctor join_hashtable.cpp:43-57): n_rows rows of row_width bytes, column i at
+ * col_offset[i] (keys first, then payload), validity bits at the front of each row.  The
+ * reference's own bucket array is not needed: the device re-buckets. */
+int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32_t row_width,
+                        const uint32_t *col_offset, const uint32_t *col_width, const uint32_t *col_flags,
+                        uint32_t n_keys, uint32_t n_payload, polr_ht **out);
+/* Same from columnar build data (DataChunks as sunk by PhysicalHashJoin::Sink,
+ * physical_hash_join.cpp:217-286).  Rows with a NULL key are dropped (join_hashtable.cpp:170-192),
+ * row ids still refer to the rows as passed. */
+int polr_ht_upload_columns(polr_ctx *ctx, const polr_col *keys, uint32_t n_keys, const polr_col *payload,
+                           uint32_t n_payload, uint64_t n_rows, polr_ht **out);
+/* Finalize as a hash table (JoinHashTable::Finalize / InsertHashes, join_hashtable.cpp:305-377). */
+int polr_ht_finalize_hash(polr_ht *ht, void *stream);
+/* Finalize as a perfect hash table (BuildPerfectHashTable, perfect_hash_join_executor.cpp:20-122):
+ * keys outside [min,max] are skipped; a duplicate inside the range returns POLR_E_DUPLICATE and
+ * leaves the handle un-finalized so the caller can polr_ht_finalize_hash it instead. */
+int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream);
+/* Upload a perfect table the reference already built (PerfectHashJoinExecutor members
+ * perfect_hash_table / bitmap_build_idx, perfect_hash_join_executor.hpp): bitmap has range+1
+ * bools, each payload column has range+1 cells. */
+int polr_pht_upload(polr_ctx *ctx, uint32_t key_width, uint32_t key_flags, int64_t min_value, int64_t max_value,
+                    const uint8_t *bitmap, const polr_col *payload, uint32_t n_payload, polr_ht **out);
+void polr_ht_destroy(polr_ht *ht);
+
+typedef struct polr_ht_info {
+	uint32_t kind;      /* 0 = not finalized, 1 = perfect, 2 = hash {key,row} slots, 3 = hash {key,start,count} slots */
+	uint32_t n_keys;
+	uint64_t n_rows;    /* rows kept (NULL keys dropped) */
+	uint64_t capacity;  /* hash slots, or range+1 */
+	uint64_t max_run;   /* longest duplicate run */
+	uint64_t device_bytes;
+	uint32_t is_dense;  /* perfect: every slot of the range filled and no NULL build key */
+	uint32_t has_null;
+} polr_ht_info;
+int polr_ht_get_info(const polr_ht *ht, polr_ht_info *info);
+/* Broadcast support (RCCL, one exchange per build side): device pointers + byte sizes of the
+ * buffers that make up the finalized table, so the caller (torch.distributed, backend "nccl")
+ * can broadcast them in place.  The receiving rank first creates a same-shaped empty table with
+ * polr_ht_alloc_like from the metadata blob. */
+int polr_ht_export(const polr_ht *ht, void *meta, uint64_t *meta_bytes, void **dev_ptrs, uint64_t *dev_bytes,
+                   uint32_t *n_buffers);
+int polr_ht_alloc_like(polr_ctx *ctx, const void *meta, uint64_t meta_bytes, polr_ht **out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pipeline = what POLARConfig::GenerateJoinOrders produces (src/parallel/polar_config.cpp:19-249):
+ * the joins of the run, where each join reads its probe key (a probe-table column, or a build
+ * column of an earlier join: left_expression_bindings, :152-229) and the candidate join orders.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct polr_join_desc {
+	polr_ht *ht;
+	uint32_t n_keys;
+	int32_t key_src_join[POLR_MAX_KEYS]; /* -1 = probe-table column, j >= 0 = payload column of join j */
+	int32_t key_src_col[POLR_MAX_KEYS];
+} polr_join_desc;
+
+int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_probe_cols, uint64_t n_probe_rows,
+                         const polr_join_desc *joins, uint32_t k, const int32_t *paths /* n_paths x k */,
+                         uint32_t n_paths, polr_pipeline **out);
+/* The tuples entering the multiplexer, in scan order, when an upstream filter thinned the source
+ * chunks (DICTIONARY/sliced vectors, vector.hpp:36-140): sel[i] = probe-table row.  NULL resets
+ * to "all rows".  flags: POLR_COL_DEVICE if sel is a device pointer. */
+int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t n_sel, uint32_t flags);
+void polr_pipeline_destroy(polr_pipeline *p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Output: a stream of fixed-capacity chunks of row ids (late materialisation).  Slot 0 = probe
+ * row, slot 1+j = build row of join j in the ORIGINAL join order, i.e. PhysicalAdaptiveUnion
+ * (src/execution/operator/polr/physical_adaptive_union.cpp:37-76) is already applied.
+ * ------------------------------------------------------------------------------------------- */
+int polr_out_create(polr_pipeline *p, uint32_t chunk_capacity, uint64_t max_chunks, polr_out **out);
+int polr_out_reset(polr_out *o, void *stream);
+int polr_out_stats(polr_out *o, void *stream, uint64_t *n_rows, uint64_t *n_chunks, uint32_t *overflowed);
+/* compacted ids to the host: dst[n_rows][1+k] (slot-major per row) */
+int polr_out_fetch_ids(polr_out *o, void *stream, uint32_t *dst, uint64_t dst_rows);
+/* Gather one output column for every output row (RowOperations::Gather, row_gather.cpp:16-173 /
+ * DataChunk::Slice for probe columns): src_join = -1 -> probe column src_col, else payload column
+ * src_col of join src_join.  dst_data/dst_valid are host or device pointers (dst_flags). */
+int polr_out_materialize(polr_out *o, void *stream, int32_t src_join, uint32_t src_col, void *dst_data,
+                         uint8_t *dst_valid, uint64_t dst_rows, uint32_t dst_flags);
+void polr_out_destroy(polr_out *o);
+
+/* ---------------------------------------------------------------------------------------------
+ * Probe: RunPath for many routed slices at once (polar_pipeline_executor.cpp:427-538 +
+ * PhysicalHashJoin::Execute physical_hash_join.cpp:637-681 + JoinHashTable::Probe /
+ * ScanStructure::NextInnerJoin join_hashtable.cpp:396-565 + ProbePerfectHashTable
+ * perfect_hash_join_executor.cpp:177-291).  A round = tuples [begin, begin+count) (positions in
+ * scan order) sent down join order `path`.  counts[r*k + j] receives the number of tuples the join
+ * at position j of that path produced: their sum over j is what RunPath feeds to
+ * PhysicalMultiplexer::AddNumIntermediates (:486-487).  out may be NULL (count only).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct polr_round {
+	uint64_t begin;
+	uint64_t count;
+	uint32_t path;
+	uint32_t emit; /* 0: count only (ALTERNATE drops the output of paths != 0, :445-447) */
+} polr_round;
+
+int polr_probe_rounds(polr_pipeline *p, void *stream, const polr_round *rounds, uint32_t n_rounds, polr_out *out,
+                      uint64_t *counts /* host, n_rounds x k, filled after an internal sync */);
+/* asynchronous form: counts stay on the device (n_rounds x k uint64), nothing is synchronised */
+int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *rounds, uint32_t n_rounds,
+                            polr_out *out, uint64_t *counts_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident multiplexer: PhysicalMultiplexer + RoutingStrategy + the reward update
+ * (src/execution/operator/polr/physical_multiplexer.cpp:100-184, routing_strategy.cpp:7-463)
+ * evaluated by a one-thread router kernel between probe launches, so a whole morsel is routed
+ * without a host round trip per routing decision.  Decisions are bit-identical to the host
+ * classes in duckdb-polr_amd/host (same double arithmetic, no contraction).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct polr_mpx_config {
+	uint32_t routing;
+	uint32_t chunk_size;       /* STANDARD_VECTOR_SIZE of the host engine (1024 in the reference snapshot) */
+	double regret_budget;
+	uint64_t init_tuple_count;
+	uint64_t atc_multiplier;
+	uint32_t log_rounds;       /* keep (path, tuples, intermediates) of every routing round */
+	uint32_t max_log_rounds;
+} polr_mpx_config;
+
+typedef struct polr_mpx_stats {
+	uint64_t num_tuples_processed;
+	uint64_t num_intermediates;
+	uint64_t num_rounds;
+	uint64_t input_tuple_count_per_path[POLR_MAX_PATHS];
+	double path_resistances[POLR_MAX_PATHS];
+} polr_mpx_stats;
+
+int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out);
+/* Route and probe source chunks [chunk_begin, chunk_end) (chunk c = tuples [c*chunk_size, ...)
+ * unless chunk offsets were set) entirely on the device; asynchronous. */
+int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out);
+int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
+/* PushFinalize's last FinalizePathRun (polar_pipeline_executor.cpp:150-151) + read back */
+int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats);
+int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tuples, uint64_t *intermediates,
+                       uint64_t max_rounds, uint64_t *n_rounds);
+void polr_mpx_destroy(polr_mpx *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -900,6 +900,7 @@ typedef struct {
 	chunk_t cached_join_chunks[ORC_MAX_PATHS][ORC_MAX_JOINS];
 	join_state_t join_states[ORC_MAX_PATHS][ORC_MAX_JOINS];
 	chunk_t mpx_output_chunk;
+	chunk_t join_out_chunk;
 	int in_process_joins[ORC_MAX_JOINS * 4];
 	int n_in_process_joins;
 	int in_process_operators; /* only the multiplexer can be in process in this pipeline */
@@ -1272,14 +1273,21 @@ static void trace_push(exec_t *e, idx_t path, idx_t tuples) {
 }
 
 /* POLARPipelineExecutor::Execute(input, result, initial_idx), polar_pipeline_executor.cpp:255-425,
- * for a pipeline whose operator list is exactly [MULTIPLEXER] (multiplexer_idx = 0,
- * initial_idx = 0): operator index 1 is the multiplexer, "past the end" is 2. */
+ * for a pipeline whose operator list is [MULTIPLEXER, <n_trailing pass-through operators>]
+ * (multiplexer_idx = 0, initial_idx = 0).  Operator index 1 is the multiplexer; indices 2.. are the
+ * operators after the join run (a PROJECTION in every plan the fixtures come from), restated as
+ * identity operators that return NEED_MORE_INPUT and need no cache (RequiresCache() false).
+ * `join_out` is intermediate_chunks[multiplexer_idx + 1] when trailing operators exist, else it
+ * aliases `result` (:261-263).  With NO trailing operator the reference returns straight out of
+ * the join-output branch (:282-290) without looking at in_process_joins -- restated as is. */
 static int polar_execute(exec_t *e, const chunk_t *input, chunk_t *result) {
 	orc_mpx_t *mpx = e->mpx;
+	const idx_t n_ops = 1 + (idx_t)e->cfg->trailing_operators;
+	chunk_t *join_out = e->cfg->trailing_operators ? &e->join_out_chunk : result;
 	int did_flush = 0;
-	int op_result = flush_in_process_joins(e, result, &did_flush);
+	int op_result = flush_in_process_joins(e, join_out, &did_flush);
 	if (op_result == OP_FINISHED) {
-		op_result = flush_join_caches(e, result, &did_flush);
+		op_result = flush_join_caches(e, join_out, &did_flush);
 	}
 	idx_t current_idx;
 	if (op_result == OP_FINISHED) {
@@ -1299,47 +1307,65 @@ static int polar_execute(exec_t *e, const chunk_t *input, chunk_t *result) {
 			current_idx++;
 		}
 	} else {
-		/* join output: current_idx = multiplexer_idx + 2 > operators.size() (:282-290) */
-		return e->in_process_operators ? OP_HAVE_MORE_OUTPUT : op_result;
+		/* join output: jump to the operator after the join sequence (:282-290) */
+		current_idx = 2;
+		if (current_idx > n_ops) {
+			return e->in_process_operators ? OP_HAVE_MORE_OUTPUT : op_result;
+		}
 	}
 	idx_t current_path = mpx->current_path_idx;
 	while (1) {
-		result->count = 0;
+		chunk_t *current_chunk = (current_idx == 1 && e->cfg->trailing_operators) ? join_out : result;
+		if (current_idx == 1 && !e->cfg->trailing_operators) {
+			current_chunk = result;
+		}
+		current_chunk->count = 0;
 		if (current_idx == 0) {
 			break;
 		}
-		/* the only operator is the multiplexer (:320-366) */
-		if (mpx->num_cache_flushing_skips > 0) {
-			chunk_t *m = &e->mpx_output_chunk;
-			m->count = input->count;
-			memcpy(m->cols[0], input->cols[0], input->count * sizeof(uint32_t));
-			orc_mpx_increase_input(mpx, m->count);
-			trace_push(e, mpx->current_path_idx, m->count);
-			run_path(e, m, result, 0);
-			mpx->num_cache_flushing_skips--;
-		} else {
-			idx_t off, cnt, path, skips;
-			int more = orc_mpx_execute(mpx, input->count, &off, &cnt, &path, &skips);
-			chunk_t *m = &e->mpx_output_chunk;
-			m->count = cnt;
-			memcpy(m->cols[0], input->cols[0] + off, cnt * sizeof(uint32_t));
-			trace_push(e, path, cnt);
-			if (more) {
-				e->in_process_operators = 1;
-			}
-			current_path = mpx->current_path_idx;
-			run_path(e, m, result, 0);
-			if (result->count == 0) {
-				if (mpx->num_cache_flushing_skips == 0) {
-					for (int i = 0; i < e->k; i++) {
-						if (e->cached_join_chunks[current_path][i].count > 0) {
-							return OP_HAVE_MORE_OUTPUT;
+		if (current_idx == 1) {
+			/* the multiplexer (:320-366) */
+			if (mpx->num_cache_flushing_skips > 0) {
+				chunk_t *m = &e->mpx_output_chunk;
+				m->count = input->count;
+				memcpy(m->cols[0], input->cols[0], input->count * sizeof(uint32_t));
+				orc_mpx_increase_input(mpx, m->count);
+				trace_push(e, mpx->current_path_idx, m->count);
+				run_path(e, m, current_chunk, 0);
+				mpx->num_cache_flushing_skips--;
+			} else {
+				idx_t off, cnt, path, skips;
+				int more = orc_mpx_execute(mpx, input->count, &off, &cnt, &path, &skips);
+				chunk_t *m = &e->mpx_output_chunk;
+				m->count = cnt;
+				memcpy(m->cols[0], input->cols[0] + off, cnt * sizeof(uint32_t));
+				trace_push(e, path, cnt);
+				if (more) {
+					e->in_process_operators = 1;
+				}
+				current_path = mpx->current_path_idx;
+				run_path(e, m, current_chunk, 0);
+				if (current_chunk->count == 0) {
+					if (mpx->num_cache_flushing_skips == 0) {
+						for (int i = 0; i < e->k; i++) {
+							if (e->cached_join_chunks[current_path][i].count > 0) {
+								return OP_HAVE_MORE_OUTPUT;
+							}
 						}
 					}
 				}
 			}
+		} else {
+			/* pass-through operator after the joins (:367-386): Execute(prev -> current), NEED_MORE_INPUT */
+			const chunk_t *prev = current_idx == 2 ? join_out : result;
+			if (prev != current_chunk) {
+				for (int c = 0; c < 1 + e->k; c++) {
+					memcpy(current_chunk->cols[c], prev->cols[c], prev->count * sizeof(uint32_t));
+				}
+				current_chunk->count = prev->count;
+			}
 		}
-		if (result->count == 0) {
+		if (current_chunk->count == 0) {
 			/* GoToSource */
 			current_idx = 0;
 			if (e->in_process_operators) {
@@ -1349,7 +1375,7 @@ static int polar_execute(exec_t *e, const chunk_t *input, chunk_t *result) {
 			continue;
 		}
 		current_idx++;
-		if (current_idx > 1) {
+		if (current_idx > n_ops) {
 			break;
 		}
 	}
@@ -1412,6 +1438,7 @@ int orc_run_pipeline(const orc_col_t *probe_cols, int n_probe_cols, idx_t n_prob
 		}
 	}
 	chunk_init(&e->mpx_output_chunk, 1, V);
+	chunk_init(&e->join_out_chunk, 1 + k, V);
 	chunk_t source_chunk, final_chunk;
 	chunk_init(&source_chunk, 1, V);
 	chunk_init(&final_chunk, 1 + k, V);
@@ -1482,6 +1509,7 @@ int orc_run_pipeline(const orc_col_t *probe_cols, int n_probe_cols, idx_t n_prob
 		}
 	}
 	chunk_destroy(&e->mpx_output_chunk);
+	chunk_destroy(&e->join_out_chunk);
 	chunk_destroy(&source_chunk);
 	chunk_destroy(&final_chunk);
 	orc_mpx_free(e->mpx);

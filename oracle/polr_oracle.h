@@ -115,6 +115,8 @@ typedef struct orc_config {
 	int32_t log_tuples_routed; /* record per-round intermediates */
 	idx_t vector_size;         /* STANDARD_VECTOR_SIZE of the build being restated (1024 in this snapshot) */
 	int32_t collect_output;    /* 0: count only; 1: keep output row ids */
+	int32_t trailing_operators; /* pass-through operators after the join run (1 = the PROJECTION every
+	                               fixture plan has; 0 = the sink follows the joins directly) */
 } orc_config_t;
 
 typedef struct orc_result {

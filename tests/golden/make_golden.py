@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- produce golden vectors by running THE REFERENCE ITSELF.
+
+Runs only in the build container (needs oracle/_ref/ref_driver + libduckdb_ref.so, compiled from
+/root/reference by oracle/ref_build.mk).  For every seeded synthetic scenario of
+polr_amd.workloads it loads the tables into the reference, runs the multiplexed join query with
+the reference's POLAR pragmas and harvests what the reference logs:
+
+  tmp/<ts>.csv        ALTERNATE: one row per source chunk x one column per join order
+                      (physical_multiplexer.cpp:194-208); other strategies: intermediates of every
+                      routing round (:210-219)
+  tmp/<ts>-intms.txt  total intermediates (polar_pipeline_executor.cpp:101-105)
+  stdout              per-path input tuple counts (physical_multiplexer.cpp:186-192)
+  result rows         -> order-insensitive digest
+
+The vectors land in tests/golden/*.json (small).  Inputs are NOT stored: tests regenerate them from
+the same seeded generator.  The known-answer cases of test/polr/polr.test are data fixtures:
+polr_test/table_{a,b,c}.csv are that test's input files, polr_test/expected.csv its 20 answer rows.
+"""
+import glob
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "duckdb-polr_amd", "python"))
+from polr_amd import workloads  # noqa: E402
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+SQLTYPE = {"int32": "INTEGER", "uint32": "UINTEGER", "int64": "BIGINT", "uint64": "UBIGINT", "int16": "SMALLINT",
+           "uint16": "USMALLINT", "int8": "TINYINT", "uint8": "UTINYINT"}
+
+
+def table_script(lines, workdir, name, cols, valid=None):
+    """emit driver commands that load `cols` (dict name -> ndarray); NULLs via a staging table."""
+    valid = valid or {}
+    n = len(next(iter(cols.values())))
+    stage = name + "__stage" if valid else name
+    lines.append("table %s %d" % (stage, n))
+    for cname, arr in cols.items():
+        path = os.path.join(workdir, "%s.%s.bin" % (name, cname))
+        np.ascontiguousarray(arr).tofile(path)
+        lines.append("col %s %s %s" % (cname, SQLTYPE[str(arr.dtype)], path))
+    for cname, v in valid.items():
+        path = os.path.join(workdir, "%s.%s.valid.bin" % (name, cname))
+        np.ascontiguousarray(v, dtype=np.uint8).tofile(path)
+        lines.append("col %s__v UTINYINT %s" % (cname, path))
+    lines.append("endtable")
+    if valid:
+        exprs = []
+        for cname in cols:
+            if cname in valid:
+                exprs.append("CASE WHEN %s__v = 0 THEN NULL ELSE %s END AS %s" % (cname, cname, cname))
+            else:
+                exprs.append(cname)
+        lines.append("sql CREATE TABLE %s AS SELECT %s FROM %s" % (name, ", ".join(exprs), stage))
+        lines.append("sql DROP TABLE %s" % stage)
+
+
+def workload_sql(wl, select="*"):
+    """the multiplexed join query in the textual join order = path 0 (join_order optimizer off)."""
+    probe = wl["probe"]["name"]
+    pcols = list(wl["probe"]["cols"].keys())
+    sql = "FROM %s" % probe
+    out_cols = ["%s.%s" % (probe, c) for c in pcols]
+    for j in wl["joins"]:
+        conds = []
+        for (sj, sc), kn in zip(j["key_src"], j["key_names"]):
+            if sj < 0:
+                left = "%s.%s" % (probe, pcols[sc])
+            else:
+                src = wl["joins"][sj]
+                left = "%s.%s" % (src["name"], list(src["payload"].keys())[sc])
+            conds.append("%s = %s.%s" % (left, j["name"], kn))
+        sql += " JOIN %s ON %s" % (j["name"], " AND ".join(conds))
+        out_cols += ["%s.%s" % (j["name"], c) for c in j["payload"].keys()]
+    if select == "*":
+        return "SELECT %s %s" % (", ".join(out_cols), sql), out_cols
+    return "SELECT %s %s" % (select, sql), out_cols
+
+
+def run_reference(wl, settings, select="*", keep_rows=True, repeat=1):
+    """returns dict(log_csv=[...], intms=int, tuple_counts=[...], rows=ndarray or None, stdout=str)"""
+    if not os.path.exists(DRIVER):
+        raise RuntimeError("reference driver missing: make -f oracle/ref_build.mk")
+    workdir = tempfile.mkdtemp(prefix="polr_golden_")
+    try:
+        lines = []
+        table_script(lines, workdir, wl["probe"]["name"], wl["probe"]["cols"], wl["probe"].get("valid"))
+        for j in wl["joins"]:
+            cols = {kn: k for kn, k in zip(j["key_names"], j["keys"])}
+            cols.update(j["payload"])
+            valid = {}
+            if j.get("key_valid"):
+                valid.update({kn: v for kn, v in zip(j["key_names"], j["key_valid"])})
+            valid.update(j.get("payload_valid", {}))
+            table_script(lines, workdir, j["name"], cols, valid)
+        lines.append("sql SET threads TO 1")
+        lines.append("sql SET disabled_optimizers TO 'join_order'")
+        for s in settings:
+            lines.append("sql " + s)
+        query, out_cols = workload_sql(wl, select)
+        lines.append("query explain EXPLAIN " + query)
+        if repeat > 1:
+            lines.append("repeat %d q %s" % (repeat, query))
+        else:
+            lines.append("query q " + query)
+        script = os.path.join(workdir, "script.txt")
+        open(script, "w").write("\n".join(lines) + "\n")
+        outdir = os.path.join(workdir, "out")
+        proc = subprocess.run([DRIVER, script, outdir], capture_output=True, text=True, check=False)
+        if proc.returncode != 0:
+            raise RuntimeError("reference driver failed:\n" + proc.stdout + proc.stderr)
+        res = {"stdout": proc.stdout, "explain": open(os.path.join(outdir, "explain.csv")).read()}
+        logs = [f for f in glob.glob(os.path.join(outdir, "tmp", "*.csv"))
+                if not f.endswith("-enumeration.csv") and "-" not in os.path.basename(f)]
+        res["log_csv"] = [open(f).read() for f in sorted(logs)]
+        intms = glob.glob(os.path.join(outdir, "tmp", "*-intms.txt"))
+        res["intms"] = [int(open(f).read().strip()) for f in sorted(intms)]
+        counts = []
+        grab = False
+        for line in proc.stdout.splitlines():
+            if line.startswith("Input tuple counts per path"):
+                grab = True
+                counts.append([])
+                continue
+            if grab and ":" in line and line.split(":")[0].strip().isdigit():
+                counts[-1].append(int(line.split(":")[1]))
+            else:
+                grab = False
+        res["tuple_counts"] = counts
+        if keep_rows:
+            rows = np.genfromtxt(os.path.join(outdir, "q.csv"), delimiter=",", skip_header=1, dtype=np.float64,
+                                 missing_values="NULL", filling_values=np.nan, ndmin=2)
+            res["rows"] = rows
+            res["out_cols"] = out_cols
+        return res
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+
+
+def rows_digest(rows):
+    """order-insensitive digest of a result set: rows as int64 (NULL -> INT64_MIN), sorted
+    lexicographically, sha256 of the bytes."""
+    a = np.where(np.isnan(rows), float(np.iinfo(np.int64).min), rows).astype(np.int64)
+    if a.size:
+        order = np.lexsort(a.T[::-1])
+        a = a[order]
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest(), int(a.shape[0])
+
+
+def parse_alt(csv_text):
+    lines = [l for l in csv_text.strip().splitlines()]
+    return [[int(x) for x in l.rstrip(",").split(",")] for l in lines[1:]]
+
+
+def parse_rounds(csv_text):
+    return [int(x) for x in csv_text.strip().splitlines()[1:]]
+
+
+SCENARIOS = {
+    "star_skew": lambda: workloads.star_skew(),
+    "star_skew_nulls": lambda: workloads.star_skew(n_fact=60_000, with_nulls=True),
+    "chain_dep": lambda: workloads.chain_dep(),
+    "fanout": lambda: workloads.fanout(),
+}
+
+ROUTINGS = ["init_once", "opportunistic", "adaptive_reinit", "dynamic", "exponential_backoff", "default_path"]
+
+
+def make_scenario(name, enumerators=("each_last_once", "each_first_once")):
+    wl = SCENARIOS[name]()
+    gold = {"scenario": name, "alternate": {}, "routing": {}}
+    for en in enumerators:
+        base = ["PRAGMA enable_polr", "PRAGMA enable_log_tuples_routed", "PRAGMA disable_caching",
+                "SET join_enumerator TO '%s'" % en, "SET max_join_orders TO 8"]
+        r = run_reference(wl, base + ["SET multiplexer_routing TO 'alternate'"])
+        if not r["log_csv"]:
+            gold["alternate"][en] = None  # POLAR did not engage (fewer than 2 join orders)
+            continue
+        digest, nrows = rows_digest(r["rows"])
+        gold["alternate"][en] = {"matrix": parse_alt(r["log_csv"][0]), "intms": r["intms"][0],
+                                 "rows_sha256": digest, "n_rows": nrows, "out_cols": r["out_cols"]}
+        gold["explain"] = r["explain"]
+        for routing in ROUTINGS:
+            for caching in (False, True):
+                s = ["PRAGMA enable_polr", "PRAGMA enable_log_tuples_routed",
+                     "SET join_enumerator TO '%s'" % en, "SET max_join_orders TO 8",
+                     "SET multiplexer_routing TO '%s'" % routing]
+                if not caching:
+                    s.append("PRAGMA disable_caching")
+                rr = run_reference(wl, s)
+                d2, n2 = rows_digest(rr["rows"])
+                key = "%s/%s/%s" % (en, routing, "cache" if caching else "nocache")
+                gold["routing"][key] = {"rounds": parse_rounds(rr["log_csv"][0]), "intms": rr["intms"][0],
+                                        "tuple_counts": rr["tuple_counts"][0], "rows_sha256": d2, "n_rows": n2}
+                assert d2 == digest, "reference result set differs between routings?!"
+        # non-default knobs for the default strategy
+        for tag, extra in (("adaptive_reinit_b0.2_i256", ["SET regret_budget TO 0.2", "SET init_tuple_count TO 256"]),
+                           ("dynamic_b0.1_m4", ["SET regret_budget TO 0.1", "SET atc_multiplier TO 4"]),
+                           ("init_once_i128", ["SET init_tuple_count TO 128"])):
+            routing = tag.split("_b")[0].split("_i")[0]
+            s = ["PRAGMA enable_polr", "PRAGMA enable_log_tuples_routed", "PRAGMA disable_caching",
+                 "SET join_enumerator TO '%s'" % en, "SET max_join_orders TO 8",
+                 "SET multiplexer_routing TO '%s'" % routing] + extra
+            rr = run_reference(wl, s)
+            gold["routing"]["%s/%s" % (en, tag)] = {"rounds": parse_rounds(rr["log_csv"][0]), "intms": rr["intms"][0],
+                                                     "tuple_counts": rr["tuple_counts"][0], "settings": extra}
+    # without POLAR at all: the plain path (same row set)
+    r0 = run_reference(wl, [])
+    gold["plain"] = dict(zip(("rows_sha256", "n_rows"), rows_digest(r0["rows"])))
+    return gold
+
+
+def main():
+    names = sys.argv[1:] or list(SCENARIOS)
+    for name in names:
+        gold = make_scenario(name)
+        path = os.path.join(HERE, name + ".json")
+        json.dump(gold, open(path, "w"), separators=(",", ":"))
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
