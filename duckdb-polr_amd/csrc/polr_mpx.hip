@@ -1,27 +1,408 @@
-// duckdb-polr_amd/csrc/polr_mpx.hip -- device-resident multiplexer (router kernel) -- placeholder
-// until the router lands; the entry points exist so the ABI is complete and fail loudly.
+// duckdb-polr_amd/csrc/polr_mpx.hip -- device-resident multiplexer.
+//
+// The reference asks its multiplexer for a route once per 1024-tuple chunk on the host
+// (POLARPipelineExecutor::Execute, src/parallel/polar_pipeline_executor.cpp:320-366).  Here the
+// multiplexer state (PhysicalMultiplexer + RoutingStrategy, polr_routing.h) lives in HBM and a
+// one-thread *router kernel* runs between two launches of the path kernel:
+//
+//     router: absorb the k counters of the previous round (AddNumIntermediates), FinalizePathRun,
+//             Route the next slice, fold the strategy's routing window (num_cache_flushing_skips whole
+//             chunks that bypass routing, :322-329) into the same round, write the round descriptor
+//     path kernel: probe that round, bump the counters
+//
+// so a whole morsel is routed with zero host round trips; the host only polls a `done` word once per
+// batch of launches.  Output row sets and per-round intermediates equal the host classes' exactly:
+// same code (polr_routing.h), same IEEE double arithmetic.
+#include <string.h>
+
+#include <algorithm>
+
 #include "polr_internal.h"
+#include "polr_routing.h"
+
+struct DevMpx {
+	polr::MultiplexerCore core;
+	uint64_t chunk_idx, chunk_end;
+	uint64_t n_tuples, n_chunks;
+	uint32_t chunk_size;
+	uint32_t done;
+	const uint64_t *chunk_offsets; // nullptr: fixed chunk_size chunks
+	uint64_t num_intermediates_total;
+	uint64_t num_rounds;
+	uint32_t log_enabled, pad;
+	uint64_t max_log, n_log;
+	uint32_t *log_path;
+	uint64_t *log_tuples;
+	uint64_t *log_inter;
+};
+
+struct polr_mpx {
+	polr_pipeline *pipe = nullptr;
+	polr_mpx_config cfg;
+	DevMpx *dev = nullptr;
+	DevRound *round_dev = nullptr;
+	uint64_t *prefix_dev = nullptr;
+	unsigned long long *counts_dev = nullptr;
+	uint64_t *chunk_offsets_dev = nullptr;
+	uint32_t *log_path = nullptr;
+	uint64_t *log_tuples = nullptr, *log_inter = nullptr;
+	uint32_t *done_host = nullptr; // pinned
+	uint32_t unit_size = 256;
+	uint64_t n_chunks = 0;
+};
+
+__device__ __forceinline__ uint64_t chunk_start(const DevMpx *m, uint64_t c) {
+	if (m->chunk_offsets) {
+		return m->chunk_offsets[c];
+	}
+	const uint64_t s = c * (uint64_t)m->chunk_size;
+	return s < m->n_tuples ? s : m->n_tuples;
+}
+
+__device__ __forceinline__ void log_round(DevMpx *m, uint64_t path, uint64_t tuples, uint64_t inter) {
+	m->num_rounds++;
+	if (m->log_enabled && m->n_log < m->max_log) {
+		m->log_path[m->n_log] = (uint32_t)path;
+		m->log_tuples[m->n_log] = tuples;
+		m->log_inter[m->n_log] = inter;
+		m->n_log++;
+	}
+}
+
+__global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_paths, uint64_t n_tuples,
+                                     uint64_t n_chunks, uint32_t *log_path, uint64_t *log_tuples,
+                                     uint64_t *log_inter) {
+	m->core.Init(cfg.routing, n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
+	m->chunk_idx = m->chunk_end = 0;
+	m->n_tuples = n_tuples;
+	m->n_chunks = n_chunks;
+	m->chunk_size = cfg.chunk_size;
+	m->done = 1;
+	m->chunk_offsets = nullptr;
+	m->num_intermediates_total = 0;
+	m->num_rounds = 0;
+	m->log_enabled = cfg.log_rounds;
+	m->max_log = cfg.max_log_rounds;
+	m->n_log = 0;
+	m->log_path = log_path;
+	m->log_tuples = log_tuples;
+	m->log_inter = log_inter;
+}
+
+__global__ void polr_mpx_set_range_kernel(DevMpx *m, uint64_t chunk_begin, uint64_t chunk_end,
+                                          const uint64_t *chunk_offsets, uint64_t n_chunks, uint64_t n_tuples) {
+	m->chunk_idx = chunk_begin;
+	m->chunk_end = chunk_end;
+	m->chunk_offsets = chunk_offsets;
+	m->n_chunks = n_chunks;
+	m->n_tuples = n_tuples;
+	m->done = chunk_begin >= chunk_end ? 1 : 0;
+}
+
+// one routing decision
+__global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *unit_prefix,
+                                       unsigned long long *counts, uint32_t k, uint32_t unit_size) {
+	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487)
+	uint64_t s = 0;
+	for (uint32_t j = 0; j < k; j++) {
+		s += counts[j];
+		counts[j] = 0;
+	}
+	polr::MultiplexerCore &core = m->core;
+	core.AddNumIntermediates(s);
+	m->num_intermediates_total += s;
+
+	round->begin = 0;
+	round->count = 0;
+	round->path = 0;
+	round->emit = 0;
+	unit_prefix[0] = 0;
+	unit_prefix[1] = 0;
+	if (m->chunk_idx >= m->chunk_end) {
+		m->done = 1;
+		return;
+	}
+	uint64_t begin, tuples, path;
+	if (core.num_cache_flushing_skips > 0) {
+		// the window continues (a previous run() ended inside it): whole chunks bypass routing
+		const uint64_t left = m->chunk_end - m->chunk_idx;
+		const uint64_t n = core.num_cache_flushing_skips < left ? core.num_cache_flushing_skips : left;
+		begin = chunk_start(m, m->chunk_idx);
+		tuples = chunk_start(m, m->chunk_idx + n) - begin;
+		core.IncreaseInputTupleCount(tuples);
+		if (core.num_cache_flushing_skips != polr::kIdxMax) {
+			core.num_cache_flushing_skips -= n;
+		}
+		m->chunk_idx += n;
+		path = core.current_path_idx;
+	} else {
+		const uint64_t c0 = chunk_start(m, m->chunk_idx);
+		const uint64_t size = chunk_start(m, m->chunk_idx + 1) - c0;
+		const uint64_t prev_path = core.current_path_idx;
+		const uint64_t prev_tuples = core.current_path_tuple_count;
+		bool finalized;
+		uint64_t closed = 0;
+		const polr::RouteDecision d = core.Execute(size, &finalized, &closed);
+		if (finalized) {
+			log_round(m, prev_path, prev_tuples, closed);
+		}
+		begin = c0 + d.offset;
+		tuples = d.count;
+		path = d.path;
+		if (!d.have_more_output) {
+			m->chunk_idx++;
+			if (core.num_cache_flushing_skips > 0 && m->chunk_idx < m->chunk_end) {
+				const uint64_t left = m->chunk_end - m->chunk_idx;
+				const uint64_t n = core.num_cache_flushing_skips < left ? core.num_cache_flushing_skips : left;
+				const uint64_t extra = chunk_start(m, m->chunk_idx + n) - chunk_start(m, m->chunk_idx);
+				core.IncreaseInputTupleCount(extra);
+				if (core.num_cache_flushing_skips != polr::kIdxMax) {
+					core.num_cache_flushing_skips -= n;
+				}
+				m->chunk_idx += n;
+				tuples += extra;
+			}
+		}
+	}
+	round->begin = begin;
+	round->count = tuples;
+	round->path = (uint32_t)path;
+	// ALTERNATE forwards only path 0's output (polar_pipeline_executor.cpp:445-447,514-523)
+	round->emit = (core.routing != polr::ALTERNATE || path == 0) ? 1u : 0u;
+	unit_prefix[1] = (tuples + unit_size - 1) / unit_size;
+}
+
+// PushFinalize's closing FinalizePathRun (polar_pipeline_executor.cpp:150-151)
+__global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, uint32_t k, polr_mpx_stats *stats) {
+	uint64_t s = 0;
+	for (uint32_t j = 0; j < k; j++) {
+		s += counts[j];
+		counts[j] = 0;
+	}
+	polr::MultiplexerCore &core = m->core;
+	core.AddNumIntermediates(s);
+	m->num_intermediates_total += s;
+	if (!core.first_mpx_run) {
+		const uint64_t path = core.current_path_idx, tuples = core.current_path_tuple_count;
+		const uint64_t closed = core.FinalizePathRun();
+		log_round(m, path, tuples, closed);
+		// a finalized run must not be finalized twice if the caller keeps routing afterwards
+		core.current_path_tuple_count = 0;
+	}
+	stats->num_tuples_processed = core.num_tuples_processed;
+	stats->num_intermediates = m->num_intermediates_total;
+	stats->num_rounds = m->num_rounds;
+	for (uint32_t i = 0; i < POLR_MAX_PATHS; i++) {
+		stats->input_tuple_count_per_path[i] = i < core.path_count ? core.input_tuple_count_per_path[i] : 0;
+		stats->path_resistances[i] = i < core.path_count ? core.path_resistances[i] : 0;
+	}
+}
 
 extern "C" {
-int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *, polr_mpx **out) {
-	if (!p || !out) {
+
+int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out) {
+	if (!p || !cfg || !out) {
 		return POLR_E_INVALID;
 	}
+	polr_ctx *ctx = p->ctx;
 	*out = nullptr;
-	POLR_FAIL(p->ctx, POLR_E_UNSUPPORTED, "device-resident multiplexer not built yet");
+	if (cfg->routing > POLR_ROUTE_EXPONENTIAL_BACKOFF) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "unknown routing strategy %u", cfg->routing);
+	}
+	if (cfg->chunk_size < 2 || cfg->chunk_size > 65536) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "chunk size %u out of range", cfg->chunk_size);
+	}
+	if (p->n_paths > polr::kMaxPaths) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "too many join orders");
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	polr_mpx *m = new polr_mpx();
+	m->pipe = p;
+	m->cfg = *cfg;
+	m->n_chunks = (p->n_tuples + cfg->chunk_size - 1) / cfg->chunk_size;
+	const uint64_t max_log = cfg->log_rounds ? std::max<uint64_t>(cfg->max_log_rounds, 1) : 1;
+	hipError_t e = hipMalloc((void **)&m->dev, sizeof(DevMpx));
+	e = e == hipSuccess ? hipMalloc((void **)&m->round_dev, sizeof(DevRound)) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->prefix_dev, 2 * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->log_inter, max_log * 8) : e;
+	e = e == hipSuccess ? hipHostMalloc((void **)&m->done_host, 64) : e;
+	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_KMAX * 8) : e;
+	if (e != hipSuccess) {
+		polr_mpx_destroy(m);
+		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer allocation failed: %s", hipGetErrorString(e));
+	}
+	m->cfg.max_log_rounds = (uint32_t)max_log;
+	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, ctx->stream, m->dev, m->cfg, p->n_paths, p->n_tuples,
+	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter);
+	e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) {
+		polr_mpx_destroy(m);
+		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer init failed: %s", hipGetErrorString(e));
+	}
+	*out = m;
+	return POLR_OK;
 }
-int polr_mpx_run(polr_mpx *, void *, uint64_t, uint64_t, polr_out *) {
-	return POLR_E_INVALID;
+
+int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks) {
+	if (!m || (!offsets && n_chunks)) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = m->pipe->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (m->chunk_offsets_dev) {
+		hipFree(m->chunk_offsets_dev);
+		m->chunk_offsets_dev = nullptr;
+	}
+	if (!offsets) {
+		m->n_chunks = (m->pipe->n_tuples + m->cfg.chunk_size - 1) / m->cfg.chunk_size;
+		return POLR_OK;
+	}
+	for (uint64_t c = 0; c < n_chunks; c++) {
+		if (offsets[c + 1] < offsets[c] || offsets[c + 1] > m->pipe->n_tuples) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "chunk offsets must be non-decreasing and within the %llu source tuples",
+			          (unsigned long long)m->pipe->n_tuples);
+		}
+	}
+	HIPCHK(ctx, hipMalloc((void **)&m->chunk_offsets_dev, (n_chunks + 1) * 8));
+	HIPCHK(ctx, hipMemcpy(m->chunk_offsets_dev, offsets, (n_chunks + 1) * 8, hipMemcpyHostToDevice));
+	m->n_chunks = n_chunks;
+	return POLR_OK;
 }
-int polr_mpx_set_chunk_offsets(polr_mpx *, const uint64_t *, uint64_t) {
-	return POLR_E_INVALID;
+
+int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out) {
+	if (!m) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = m->pipe;
+	polr_ctx *ctx = p->ctx;
+	if (chunk_begin > chunk_end || chunk_end > m->n_chunks) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks",
+		          (unsigned long long)chunk_begin, (unsigned long long)chunk_end, (unsigned long long)m->n_chunks);
+	}
+	if (out && out->pipe != p) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "output object belongs to another pipeline");
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	const bool materialize = out != nullptr;
+	uint32_t unit_unused, max_blocks;
+	int rc = polr_plan_launch(p, materialize, p->n_tuples, &unit_unused, &max_blocks);
+	if (rc) {
+		return rc;
+	}
+	DevOut dout;
+	memset(&dout, 0, sizeof(dout));
+	if (out) {
+		dout = out->dev;
+		out->stats_valid = false;
+	}
+	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
+	const DevPipeline *dpd = materialize ? p->dev_mat : p->dev_count;
+	hipLaunchKernelGGL(polr_mpx_set_range_kernel, dim3(1), dim3(1), 0, st, m->dev, chunk_begin, chunk_end,
+	                   (const uint64_t *)m->chunk_offsets_dev, m->n_chunks, p->n_tuples);
+	const int batch = 16;
+	for (;;) {
+		for (int i = 0; i < batch; i++) {
+			hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(1), 0, st, m->dev, m->round_dev, m->prefix_dev,
+			                   m->counts_dev, p->k, m->unit_size);
+			hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
+			                                       m->unit_size, dout, m->counts_dev);
+			if (e != hipSuccess) {
+				POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
+			}
+		}
+		HIPCHK(ctx, hipMemcpyAsync(m->done_host, &m->dev->done, 4, hipMemcpyDeviceToHost, st));
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		if (*m->done_host) {
+			break;
+		}
+	}
+	return POLR_OK;
 }
-int polr_mpx_finish(polr_mpx *, void *, polr_mpx_stats *) {
-	return POLR_E_INVALID;
+
+int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
+	if (!m || !stats) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = m->pipe->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	polr_mpx_stats *sd = nullptr;
+	HIPCHK(ctx, hipMalloc((void **)&sd, sizeof(polr_mpx_stats)));
+	hipLaunchKernelGGL(polr_mpx_finish_kernel, dim3(1), dim3(1), 0, st, m->dev, m->counts_dev, m->pipe->k, sd);
+	hipError_t e = hipMemcpyAsync(stats, sd, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st);
+	e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+	hipFree(sd);
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer finish failed: %s", hipGetErrorString(e));
+	}
+	return POLR_OK;
 }
-int polr_mpx_fetch_log(polr_mpx *, void *, uint32_t *, uint64_t *, uint64_t *, uint64_t, uint64_t *) {
-	return POLR_E_INVALID;
+
+int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tuples, uint64_t *intermediates,
+                       uint64_t max_rounds, uint64_t *n_rounds) {
+	if (!m || !n_rounds) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = m->pipe->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	DevMpx h;
+	HIPCHK(ctx, hipMemcpyAsync(&h, m->dev, sizeof(DevMpx), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	const uint64_t n = std::min<uint64_t>(h.n_log, max_rounds);
+	*n_rounds = n;
+	if (n) {
+		if (path) {
+			HIPCHK(ctx, hipMemcpyAsync(path, m->log_path, n * 4, hipMemcpyDeviceToHost, st));
+		}
+		if (tuples) {
+			HIPCHK(ctx, hipMemcpyAsync(tuples, m->log_tuples, n * 8, hipMemcpyDeviceToHost, st));
+		}
+		if (intermediates) {
+			HIPCHK(ctx, hipMemcpyAsync(intermediates, m->log_inter, n * 8, hipMemcpyDeviceToHost, st));
+		}
+		HIPCHK(ctx, hipStreamSynchronize(st));
+	}
+	return POLR_OK;
 }
-void polr_mpx_destroy(polr_mpx *) {
+
+void polr_mpx_destroy(polr_mpx *m) {
+	if (!m) {
+		return;
+	}
+	hipSetDevice(m->pipe->ctx->device);
+	if (m->dev) {
+		hipFree(m->dev);
+	}
+	if (m->round_dev) {
+		hipFree(m->round_dev);
+	}
+	if (m->prefix_dev) {
+		hipFree(m->prefix_dev);
+	}
+	if (m->counts_dev) {
+		hipFree(m->counts_dev);
+	}
+	if (m->chunk_offsets_dev) {
+		hipFree(m->chunk_offsets_dev);
+	}
+	if (m->log_path) {
+		hipFree(m->log_path);
+	}
+	if (m->log_tuples) {
+		hipFree(m->log_tuples);
+	}
+	if (m->log_inter) {
+		hipFree(m->log_inter);
+	}
+	if (m->done_host) {
+		hipHostFree(m->done_host);
+	}
+	delete m;
 }
-}
+
+} // extern "C"

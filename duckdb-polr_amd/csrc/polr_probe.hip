@@ -595,10 +595,15 @@ template <int W>
 static hipError_t launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const DevPipeline *pipe,
                            const DevRound *rounds, const uint64_t *unit_prefix, uint32_t n_rounds,
                            uint32_t unit_size, DevOut out, unsigned long long *counts) {
-	hipError_t e = hipFuncSetAttribute((const void *)polr_path_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
-	                                   (int)lds);
-	if (e != hipSuccess) {
-		return e;
+	// raise the dynamic-LDS limit once per (W, size): a host call we do not want on every launch
+	static size_t lds_set = 0;
+	if (lds > lds_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)polr_path_kernel<W>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) {
+			return e;
+		}
+		lds_set = lds;
 	}
 	hipLaunchKernelGGL(polr_path_kernel<W>, grid, block, lds, stream, pipe, rounds, unit_prefix, n_rounds, unit_size,
 	                   out, counts);
