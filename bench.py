@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""bench.py -- probe-tuples/s of the POLAR multiplexed hash-join pipeline on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--workload job_light_01] [--routing adaptive_reinit]
+
+One *step* = one complete pass of the hot path over the workload's probe side: a fresh multiplexer
+routes every source chunk (device-resident router), the path kernel probes the routed slices through
+the bank of join orders and feeds the per-join counters back into the reward -- inputs (probe columns,
+selection, build tables) already resident in HBM when the clock starts.  The sink is COUNT(*) (only
+counters leave the device), as in JOB-light.  Default workload = BASELINE.json configs[1]
+("JOB-light 3-way join on 1 MI355X, single POLR pipeline, build sides in HBM") at the IMDB
+cardinalities, synthetic data of that shape (no dataset access offline).
+
+Multi-GPU (torchrun, one rank per GPU): the path shards by probe partition -- every rank owns a
+same-sized partition of the probe side (weak scaling) and its own multiplexer, exactly like one
+PipelineExecutor per thread in the reference; the build sides are built on rank 0 and broadcast
+once over RCCL before the clock starts; no collective on the data path.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel =
+polr_path_kernel, algorithmic bytes per SURVEY.md 8(d) over HIP-event kernel time) and
+`cpu_baseline` (the reference itself, compiled from its sources by oracle/ref_build.mk, timed on
+this box's host cores; falls back to the oracle port when the reference build is absent).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "duckdb-polr_amd", "python"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+class _DevBuf:
+    """zero-copy view of a library-owned device buffer for torch (RCCL broadcast)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def ref_capacity(n):
+    """PointerTableCapacity of the reference's chained table (join_hashtable.hpp:265-267)"""
+    want = max(2 * n, (262136 // 8) + 1)
+    p = 1
+    while p < want:
+        p <<= 1
+    return p
+
+
+def algorithmic_bytes(wl, joins_info, paths, tuples_per_path, stage_out):
+    """per input tuple of join j:  chained  K + 8 + c(1+K+8) + m(P+4+P),
+    perfect  K + 1 + m(4+4);  c = m + n_build/capacity (matching rows + expected bucket collisions at
+    the reference's load factor), m = stage outputs / stage inputs, P = payload bytes gathered (0: the
+    sink is COUNT(*), nothing is materialised).  Summed over every routed round."""
+    total = 0.0
+    for p, path in enumerate(paths):
+        inp = float(tuples_per_path[p])
+        for pos, j in enumerate(path):
+            out = float(stage_out[p][pos])
+            info = joins_info[j]
+            K = info["key_bytes"]
+            if info["perfect"]:
+                total += inp * (K + 1) + out * 8
+            else:
+                alpha = info["n_rows"] / float(ref_capacity(info["n_rows"]))
+                total += inp * (K + 8 + alpha * (1 + K + 8)) + out * ((1 + K + 8) + 4)
+            inp = out
+    return total
+
+
+def build_workload(name, scale, seed):
+    from polr_amd import workloads
+    if name == "job_light_01":
+        return workloads.job_light_01(scale=scale, seed=seed)
+    if name == "ssb_skew_q41":
+        return workloads.ssb_skew_q41(sf=scale, seed=seed)
+    if name == "star_skew":
+        return workloads.star_skew(n_fact=int(2_000_000 * scale), seed=seed)
+    raise SystemExit("unknown workload %s" % name)
+
+
+def chunk_offsets_for(sel, n_rows, V):
+    """source chunk boundaries in selection order: the scan emits one (thinned) chunk per V-row
+    vector, never an empty one"""
+    if sel is None:
+        return None
+    bounds = np.searchsorted(sel, np.arange(0, n_rows + V, V, dtype=np.int64)).astype(np.uint64)
+    keep = np.concatenate([[True], bounds[1:] != bounds[:-1]])
+    return bounds[keep]
+
+
+def cpu_baseline(wl, routing, n_tuples, args):
+    """rank 0, N=1 only.  The reference's own CPU POLAR path on the same tables and the same pinned
+    pipeline (same routing strategy), timed by its own PRAGMA enable_measure_pipeline."""
+    from oracle import ref_run
+    nproc = os.cpu_count() or 1
+    if ref_run.available() and "ref" in wl:
+        ref = wl["ref"]
+        settings = list(ref["settings"]) + ["SET multiplexer_routing TO '%s'" % routing,
+                                            "SET join_enumerator TO 'each_last_once'"]
+        best = None
+        detail = {}
+        for threads in sorted(set([1, nproc])):
+            ms, wall, result = ref_run.time_polar_pipeline(ref["tables"], ref["query"], settings, threads, repeat=5)
+            if not ms:
+                continue
+            med = float(np.median(ms))
+            detail["threads_%d_pipeline_ms" % threads] = round(med, 3)
+            v = n_tuples / (med / 1e3)
+            if best is None or v > best[0]:
+                best = (v, threads)
+        if best:
+            return {"value": best[0], "unit": "probe-tuples/s", "cores": best[1], "kind": "reference",
+                    "sample": "whole workload, median of 5 runs of the reference's POLAR pipeline "
+                              "(Pipeline::Schedule->Finalize incl. scan+filter+count sink), threads in {1,%d}" % nproc,
+                    **detail}
+    # port: the oracle restatement, single thread, on a bounded prefix of the probe side
+    from oracle import polr_oracle as orc
+    from polr_amd import workloads
+    k = len(wl["joins"])
+    ojoins = []
+    for j in wl["joins"]:
+        ht = orc.HashTable(j["keys"], list(j["payload"].values()))
+        if j.get("perfect") is not None:
+            ht.make_perfect(*j["perfect"])
+        ojoins.append(orc.JoinSpec(ht, j["key_src"]))
+    sel = wl["probe"].get("filter_sel")
+    sample = min(n_tuples, 4_000_000)
+    cols = list(wl["probe"]["cols"].values())
+    if sel is not None:
+        sel = sel[:sample]
+    else:
+        cols = [c[:sample] for c in cols]
+    t0 = time.time()
+    orc.run_pipeline(cols, ojoins, workloads.default_paths(k), routing=routing, collect_output=False, sel=sel)
+    dt = time.time() - t0
+    return {"value": sample / dt, "unit": "probe-tuples/s", "cores": 1, "kind": "port",
+            "sample": "first %d probe tuples through the oracle restatement (single thread)" % sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="job_light_01")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--routing", default="adaptive_reinit")
+    ap.add_argument("--regret-budget", type=float, default=0.01)
+    ap.add_argument("--init-tuple-count", type=int, default=1024)
+    ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from polr_amd import capi, workloads
+    ctx = capi.Context(local_rank)  # raises without the HIP library / a gfx950 device: no fallback
+    V = args.chunk_size
+
+    # ---- workload: same build sides everywhere, one probe partition per rank (weak scaling) -------
+    wl0 = build_workload(args.workload, args.scale, workloads.SEED)
+    wl = wl0 if rank == 0 else build_workload(args.workload, args.scale, workloads.SEED + 7919 * rank)
+    k = len(wl0["joins"])
+    paths = workloads.default_paths(k, "each_last_once")
+
+    # build sides: rank 0 builds in HBM, everyone else receives them over RCCL (one broadcast per buffer)
+    joins = []
+    joins_info = []
+    for j in wl0["joins"]:
+        joins_info.append({"key_bytes": sum(a.dtype.itemsize for a in j["keys"]), "n_rows": len(j["keys"][0]),
+                           "perfect": False})
+    t_build0 = time.time()
+    if rank == 0:
+        joins = capi.build_joins(ctx, wl0)
+    bcast_bytes = 0
+    if world > 1:
+        new_joins = []
+        for x in range(k):
+            if rank == 0:
+                meta, bufs = joins[x][0].export()
+                meta_t = torch.tensor(list(meta), dtype=torch.uint8, device=dev)
+                n_meta = torch.tensor([len(meta)], dtype=torch.int64, device=dev)
+            else:
+                n_meta = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.broadcast(n_meta, 0)
+            if rank != 0:
+                meta_t = torch.zeros(int(n_meta.item()), dtype=torch.uint8, device=dev)
+            dist.broadcast(meta_t, 0)
+            if rank != 0:
+                ht = capi.HashTable.alloc_like(ctx, bytes(meta_t.cpu().numpy().tobytes()))
+                _m, bufs = ht.export()
+                new_joins.append((ht, wl0["joins"][x]["key_src"]))
+            for ptr, nbytes in bufs:
+                t = torch.as_tensor(_DevBuf(ptr, nbytes), device=dev)
+                dist.broadcast(t, 0)
+                bcast_bytes += nbytes
+        if rank != 0:
+            joins = new_joins
+        torch.cuda.synchronize()
+    t_build = time.time() - t_build0
+    for x in range(k):
+        joins_info[x]["perfect"] = joins[x][0].info()["kind"] == 1
+
+    # probe side resident in HBM as torch tensors (plumbing only)
+    probe = wl["probe"]
+    names = list(probe["cols"].keys())
+    n_rows = len(probe["cols"][names[0]])
+    tens = [torch.from_numpy(np.ascontiguousarray(probe["cols"][n])).to(dev) for n in names]
+    cols = [capi.dev_col(t.data_ptr(), t.element_size(), signed=probe["cols"][n].dtype.kind == "i")
+            for t, n in zip(tens, names)]
+    pipe = capi.Pipeline(ctx, cols, n_rows, joins, paths)
+    sel = probe.get("filter_sel")
+    sel_t = None
+    if sel is not None:
+        sel_t = torch.from_numpy(np.ascontiguousarray(sel)).to(dev)
+        pipe.set_selection(sel_t.data_ptr(), device=True, n=len(sel))
+    n_tuples = len(sel) if sel is not None else n_rows
+    budget = args.regret_budget
+    if args.routing == "exponential_backoff":
+        budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
+    mpx = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
+                                 init_tuple_count=args.init_tuple_count, log_rounds=False)
+    offs = chunk_offsets_for(sel, n_rows, V)
+    if offs is not None:
+        mpx.set_chunk_offsets(offs)
+        n_chunks = len(offs) - 1
+    else:
+        n_chunks = (n_tuples + V - 1) // V
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        mpx.reset(stream)
+        mpx.run(0, n_chunks, stream=stream)
+        return mpx.finish(stream)
+
+    for _ in range(args.warmup):
+        st = step()
+    mpx.kernel_time()
+    if not args.no_kernel_events:
+        mpx.enable_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = mpx.kernel_time()
+    mpx.enable_timing(False)
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tup_t = torch.tensor([float(n_tuples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tup_t, op=dist.ReduceOp.SUM)
+    dt_max = float(dt_t.item())
+    total_tuples = float(tup_t.item())
+
+    if rank == 0:
+        value = total_tuples * args.steps / dt_max
+        alg = algorithmic_bytes(wl, joins_info, paths.tolist(), st["input_tuple_count_per_path"], st["stage_out"])
+        roof = None
+        if launches:
+            sec = kernel_ms / 1e3 / args.steps  # path-kernel time of one step (all its routing rounds)
+            achieved = alg / sec / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_step")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel": "polr_path_kernel", "algorithmic_bytes_per_step": round(alg),
+                    "kernel_ms_per_step": round(kernel_ms / args.steps, 4),
+                    "launches_per_step": launches / args.steps}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(wl0, args.routing, n_tuples, args)
+                cpu["value"] = round(cpu["value"], 1)
+            except Exception as e:  # the baseline must never take the measurement down
+                cpu = {"value": None, "error": str(e)[:200]}
+        line = {
+            "metric": "probe-tuples/s", "value": round(value, 1), "unit": "tuples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u64 (hash + compare); f64 reward",
+            "data": "synthetic",
+            "config": {"workload": "%s (JOB-light 01 shape, IMDB cardinalities x%.3g: %d probe tuples after the "
+                                   "company_type_id filter, builds title %d + movie_info_idx %d rows)" %
+                                   (args.workload, args.scale, n_tuples, joins_info[0]["n_rows"],
+                                    joins_info[1]["n_rows"]) if args.workload == "job_light_01" else args.workload,
+                       "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
+                       "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
+                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples},
+            "total_intermediates": int(st["num_intermediates"]),
+            "routing_rounds": int(st["num_rounds"]),
+            "tuples_per_path": st["input_tuple_count_per_path"],
+            "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu and cpu.get("value"):
+            line["gpu_over_cpu"] = round(value / cpu["value"], 2)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "polr_internal.h"
 #include "polr_routing.h"
@@ -34,6 +35,8 @@ struct DevMpx {
 	uint32_t *log_path;
 	uint64_t *log_tuples;
 	uint64_t *log_inter;
+	uint64_t last_path; // path of the round whose counters are still to be absorbed
+	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
 };
 
 struct polr_mpx {
@@ -49,7 +52,24 @@ struct polr_mpx {
 	uint32_t *done_host = nullptr; // pinned
 	uint32_t unit_size = 256;
 	uint64_t n_chunks = 0;
+	// optional per-launch timing (measurement only)
+	bool timing = false;
+	std::vector<hipEvent_t> ev_start, ev_stop;
+	size_t ev_used = 0;
+	double timed_ms = 0;
+	uint64_t timed_launches = 0;
 };
+
+static void drain_events(polr_mpx *m) {
+	for (size_t i = 0; i < m->ev_used; i++) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, m->ev_start[i], m->ev_stop[i]) == hipSuccess) {
+			m->timed_ms += ms;
+			m->timed_launches++;
+		}
+	}
+	m->ev_used = 0;
+}
 
 __device__ __forceinline__ uint64_t chunk_start(const DevMpx *m, uint64_t c) {
 	if (m->chunk_offsets) {
@@ -87,6 +107,12 @@ __global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_
 	m->log_path = log_path;
 	m->log_tuples = log_tuples;
 	m->log_inter = log_inter;
+	m->last_path = 0;
+	for (uint32_t p = 0; p < POLR_MAX_PATHS; p++) {
+		for (uint32_t j = 0; j < POLR_MAX_JOINS; j++) {
+			m->stage_out[p][j] = 0;
+		}
+	}
 }
 
 __global__ void polr_mpx_set_range_kernel(DevMpx *m, uint64_t chunk_begin, uint64_t chunk_end,
@@ -106,6 +132,7 @@ __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *uni
 	uint64_t s = 0;
 	for (uint32_t j = 0; j < k; j++) {
 		s += counts[j];
+		m->stage_out[m->last_path][j] += counts[j];
 		counts[j] = 0;
 	}
 	polr::MultiplexerCore &core = m->core;
@@ -164,6 +191,7 @@ __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *uni
 			}
 		}
 	}
+	m->last_path = path;
 	round->begin = begin;
 	round->count = tuples;
 	round->path = (uint32_t)path;
@@ -177,6 +205,7 @@ __global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, ui
 	uint64_t s = 0;
 	for (uint32_t j = 0; j < k; j++) {
 		s += counts[j];
+		m->stage_out[m->last_path][j] += counts[j];
 		counts[j] = 0;
 	}
 	polr::MultiplexerCore &core = m->core;
@@ -195,6 +224,9 @@ __global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, ui
 	for (uint32_t i = 0; i < POLR_MAX_PATHS; i++) {
 		stats->input_tuple_count_per_path[i] = i < core.path_count ? core.input_tuple_count_per_path[i] : 0;
 		stats->path_resistances[i] = i < core.path_count ? core.path_resistances[i] : 0;
+		for (uint32_t j = 0; j < POLR_MAX_JOINS; j++) {
+			stats->stage_out[i][j] = m->stage_out[i][j];
+		}
 	}
 }
 
@@ -308,18 +340,68 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 		for (int i = 0; i < batch; i++) {
 			hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(1), 0, st, m->dev, m->round_dev, m->prefix_dev,
 			                   m->counts_dev, p->k, m->unit_size);
+			size_t ev = 0;
+			if (m->timing) {
+				ev = m->ev_used++;
+				if (ev >= m->ev_start.size()) {
+					hipEvent_t a, b;
+					HIPCHK(ctx, hipEventCreate(&a));
+					HIPCHK(ctx, hipEventCreate(&b));
+					m->ev_start.push_back(a);
+					m->ev_stop.push_back(b);
+				}
+				HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
+			}
 			hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
 			                                       m->unit_size, dout, m->counts_dev);
 			if (e != hipSuccess) {
 				POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
 			}
+			if (m->timing) {
+				HIPCHK(ctx, hipEventRecord(m->ev_stop[ev], st));
+			}
 		}
 		HIPCHK(ctx, hipMemcpyAsync(m->done_host, &m->dev->done, 4, hipMemcpyDeviceToHost, st));
 		HIPCHK(ctx, hipStreamSynchronize(st));
+		if (m->timing) {
+			drain_events(m);
+		}
 		if (*m->done_host) {
 			break;
 		}
 	}
+	return POLR_OK;
+}
+
+int polr_mpx_reset(polr_mpx *m, void *stream) {
+	if (!m) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = m->pipe->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_KMAX * 8, st));
+	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
+	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter);
+	return POLR_OK;
+}
+
+int polr_mpx_enable_timing(polr_mpx *m, int enable) {
+	if (!m) {
+		return POLR_E_INVALID;
+	}
+	m->timing = enable != 0;
+	return POLR_OK;
+}
+
+int polr_mpx_kernel_time(polr_mpx *m, double *total_ms, uint64_t *n_launches) {
+	if (!m || !total_ms || !n_launches) {
+		return POLR_E_INVALID;
+	}
+	*total_ms = m->timed_ms;
+	*n_launches = m->timed_launches;
+	m->timed_ms = 0;
+	m->timed_launches = 0;
 	return POLR_OK;
 }
 
@@ -401,6 +483,12 @@ void polr_mpx_destroy(polr_mpx *m) {
 	}
 	if (m->done_host) {
 		hipHostFree(m->done_host);
+	}
+	for (auto e : m->ev_start) {
+		hipEventDestroy(e);
+	}
+	for (auto e : m->ev_stop) {
+		hipEventDestroy(e);
 	}
 	delete m;
 }

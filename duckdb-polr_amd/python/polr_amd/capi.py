@@ -29,7 +29,7 @@ EXPORTS = [
     "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
-    "polr_mpx_destroy",
+    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time",
 ]
 
 
@@ -66,7 +66,8 @@ class MpxConfig(C.Structure):
 
 class MpxStats(C.Structure):
     _fields_ = [("num_tuples_processed", C.c_uint64), ("num_intermediates", C.c_uint64), ("num_rounds", C.c_uint64),
-                ("input_tuple_count_per_path", C.c_uint64 * MAX_PATHS), ("path_resistances", C.c_double * MAX_PATHS)]
+                ("input_tuple_count_per_path", C.c_uint64 * MAX_PATHS), ("path_resistances", C.c_double * MAX_PATHS),
+                ("stage_out", (C.c_uint64 * MAX_JOINS) * MAX_PATHS)]
 
 
 _lib = None
@@ -119,6 +120,9 @@ def load():
     L.polr_mpx_fetch_log.argtypes = [vp, vp, vp, vp, vp, u64, P(u64)]
     L.polr_mpx_destroy.argtypes = [vp]
     L.polr_mpx_destroy.restype = None
+    L.polr_mpx_reset.argtypes = [vp, vp]
+    L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
+    L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
     _lib = L
     return L
 
@@ -402,7 +406,19 @@ class DeviceMultiplexer:
         return {"num_tuples_processed": st.num_tuples_processed, "num_intermediates": st.num_intermediates,
                 "num_rounds": st.num_rounds,
                 "input_tuple_count_per_path": [st.input_tuple_count_per_path[i] for i in range(P)],
-                "path_resistances": [st.path_resistances[i] for i in range(P)]}
+                "path_resistances": [st.path_resistances[i] for i in range(P)],
+                "stage_out": [[st.stage_out[i][j] for j in range(self.pipe.k)] for i in range(P)]}
+
+    def reset(self, stream=None):
+        self.ctx.check(self.ctx.L.polr_mpx_reset(self.h, stream))
+
+    def enable_timing(self, on=True):
+        self.ctx.check(self.ctx.L.polr_mpx_enable_timing(self.h, int(on)))
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self.ctx.check(self.ctx.L.polr_mpx_kernel_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def fetch_log(self, stream=None):
         n = C.c_uint64()

@@ -175,7 +175,16 @@ def job_light_01(scale=1.0, seed=SEED):
     jmi = {"name": "movie_info_idx", "keys": [mi_movie[mi_keep]], "key_names": ["movie_id"], "payload": {},
            "key_src": [(-1, 0)], "perfect": None,
            "unfiltered": {"movie_id": mi_movie, "info_type_id": mi_type}, "filter_sql": "info_type_id=112"}
-    return {"name": "job_light_01", "probe": probe, "joins": [jt, jmi]}
+    # how the same pipeline reads for the reference: explicit left-deep join order (path 0), both
+    # joins probed with mc.movie_id (t.id = mc.movie_id = mi_idx.movie_id is one equivalence class)
+    ref = {"tables": {"movie_companies": {"movie_id": mc_movie, "company_type_id": mc_ctype},
+                      "title": {"id": t_id},
+                      "movie_info_idx": {"movie_id": mi_movie, "info_type_id": mi_type}},
+           "settings": ["SET disabled_optimizers TO 'join_order'"],
+           "query": "SELECT COUNT(*) FROM movie_companies mc JOIN title t ON mc.movie_id = t.id "
+                    "JOIN movie_info_idx mi_idx ON mc.movie_id = mi_idx.movie_id "
+                    "WHERE mi_idx.info_type_id = 112 AND mc.company_type_id = 2"}
+    return {"name": "job_light_01", "probe": probe, "joins": [jt, jmi], "ref": ref}
 
 
 # -------------------------------------------------------------------------------------------------

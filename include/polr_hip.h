@@ -220,6 +220,9 @@ typedef struct polr_mpx_stats {
 	uint64_t num_rounds;
 	uint64_t input_tuple_count_per_path[POLR_MAX_PATHS];
 	double path_resistances[POLR_MAX_PATHS];
+	/* tuples produced by the join at position j of join order p, summed over all rounds routed to p
+	 * (the per-operator `elements` the reference's profiler reports, query_profiler.cpp:383-404) */
+	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
 } polr_mpx_stats;
 
 int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out);
@@ -227,6 +230,12 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
  * unless chunk offsets were set) entirely on the device; asynchronous. */
 int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out);
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
+/* fresh MultiplexerState (a new PipelineExecutor / a new pass over the source) */
+int polr_mpx_reset(polr_mpx *m, void *stream);
+/* bracket every path-kernel launch of polr_mpx_run with HIP events on the launch stream and report
+ * the summed device time and launch count since the last call (measurement only) */
+int polr_mpx_enable_timing(polr_mpx *m, int enable);
+int polr_mpx_kernel_time(polr_mpx *m, double *total_ms, uint64_t *n_launches);
 /* PushFinalize's last FinalizePathRun (polar_pipeline_executor.cpp:150-151) + read back */
 int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats);
 int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tuples, uint64_t *intermediates,
