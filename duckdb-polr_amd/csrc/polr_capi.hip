@@ -871,6 +871,47 @@ static void fill_dev_join(DevJoin *dj, const polr_join_desc *jd, const polr_ht *
 	dj->payload = ht->payload_dev;
 }
 
+// resolve every (join order, position) of a pipeline variant into a StageDesc (see polr_device.h)
+static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std::vector<StageDesc> &out) {
+	out.assign((size_t)dp.n_paths * POLR_KMAX, StageDesc());
+	for (uint32_t q = 0; q < dp.n_paths; q++) {
+		for (uint32_t pos = 0; pos < dp.k; pos++) {
+			const uint32_t j = dp.paths[q].order[pos];
+			const DevJoin &dj = dp.joins[j];
+			const polr_ht *ht = p->hts[j];
+			StageDesc &d = out[(size_t)q * POLR_KMAX + pos];
+			memset(&d, 0, sizeof(d));
+			d.kind = dj.kind;
+			d.n_keys = dj.n_keys;
+			d.key_signed = dj.key_signed;
+			d.out_slot = dp.slot_of_join[j];
+			for (uint32_t c = 0; c < dj.n_keys; c++) {
+				d.key_width[c] = dj.key_width[c];
+				const int32_t sj = dj.key_src_join[c];
+				const int32_t sc = dj.key_src_col[c];
+				if (sj < 0) {
+					d.key_slot[c] = 0;
+					d.key_data[c] = p->probe_cols[sc].data;
+					d.key_valid[c] = p->probe_cols[sc].valid;
+				} else {
+					const polr_ht *src = p->hts[sj];
+					const OwnedCol &col = src->kind == KIND_PERFECT ? src->pcols[sc] : src->payload[sc];
+					d.key_slot[c] = dp.slot_of_join[sj];
+					d.key_data[c] = col.data;
+					d.key_valid[c] = col.valid;
+				}
+			}
+			d.table = ht->table;
+			d.rowids = ht->rowids;
+			d.mask = dj.mask;
+			d.min_value = dj.min_value;
+			d.range = dj.range;
+			d.sentinel_start = dj.sentinel_start;
+			d.sentinel_count = dj.sentinel_count;
+		}
+	}
+}
+
 int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_probe_cols, uint64_t n_probe_rows,
                          const polr_join_desc *joins, uint32_t k, const int32_t *paths, uint32_t n_paths,
                          polr_pipeline **out) {
@@ -999,7 +1040,20 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 			}
 		}
 		c.W = w;
-		hipError_t e = hipMalloc((void **)&p->dev_mat, sizeof(DevPipeline));
+		std::vector<StageDesc> sd_mat, sd_count;
+		build_stage_descs(p, p->host_mat, sd_mat);
+		build_stage_descs(p, p->host_count, sd_count);
+		hipError_t e = hipMalloc((void **)&p->stages_mat, sd_mat.size() * sizeof(StageDesc));
+		e = e == hipSuccess ? hipMalloc((void **)&p->stages_count, sd_count.size() * sizeof(StageDesc)) : e;
+		e = e == hipSuccess ? hipMemcpy(p->stages_mat, sd_mat.data(), sd_mat.size() * sizeof(StageDesc),
+		                                hipMemcpyHostToDevice)
+		                    : e;
+		e = e == hipSuccess ? hipMemcpy(p->stages_count, sd_count.data(), sd_count.size() * sizeof(StageDesc),
+		                                hipMemcpyHostToDevice)
+		                    : e;
+		p->host_mat.stages = p->stages_mat;
+		p->host_count.stages = p->stages_count;
+		e = e == hipSuccess ? hipMalloc((void **)&p->dev_mat, sizeof(DevPipeline)) : e;
 		e = e == hipSuccess ? hipMalloc((void **)&p->dev_count, sizeof(DevPipeline)) : e;
 		e = e == hipSuccess ? hipMemcpy(p->dev_mat, &p->host_mat, sizeof(DevPipeline), hipMemcpyHostToDevice) : e;
 		e = e == hipSuccess ? hipMemcpy(p->dev_count, &p->host_count, sizeof(DevPipeline), hipMemcpyHostToDevice) : e;
@@ -1073,11 +1127,20 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	if (p->dev_count) {
 		hipFree(p->dev_count);
 	}
+	if (p->stages_mat) {
+		hipFree(p->stages_mat);
+	}
+	if (p->stages_count) {
+		hipFree(p->stages_count);
+	}
 	if (p->rounds_dev) {
 		hipFree(p->rounds_dev);
 	}
 	if (p->prefix_dev) {
 		hipFree(p->prefix_dev);
+	}
+	if (p->unit_sizes_dev) {
+		hipFree(p->unit_sizes_dev);
 	}
 	if (p->counts_dev) {
 		hipFree(p->counts_dev);
@@ -1317,9 +1380,22 @@ void polr_out_destroy(polr_out *o) {
 // ---------------------------------------------------------------------------------------------------
 // Probe launches
 // ---------------------------------------------------------------------------------------------------
-// Launch geometry for `total_tuples` tuples: 256-thread workgroups (4 independent waves), as many
-// workgroups per CU as the per-wave LDS queues admit (<= 8), units of 64..1024 tuples so that a small
-// routing round still spreads over the chip while a table-sized round keeps >= 4 units per wave.
+// Launch geometry: 256-thread workgroups (4 independent waves); the grid never exceeds what is
+// resident at once (occupancy of the instantiation x CUs), waves grid-stride over units of 64..1024
+// tuples sized so that a small routing round still spreads over the chip while a table-sized round
+// gives every resident wave a few units.
+uint32_t polr_resident_waves(polr_pipeline *p, bool materialize) {
+	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
+	int &cached = materialize ? p->blocks_per_cu_mat : p->blocks_per_cu_count;
+	if (cached == 0) {
+		cached = polr_path_occupancy(dp.k, dp.W, 4);
+		if (cached > 8) {
+			cached = 8;
+		}
+	}
+	return (uint32_t)p->ctx->n_cus * (uint32_t)cached * 4u;
+}
+
 int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, uint32_t *unit_size,
                      uint32_t *n_blocks_max) {
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
@@ -1328,15 +1404,12 @@ int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, 
 		p->ctx->err = "per-workgroup LDS queues exceed 160 KB (too many joins x carried ids)";
 		return POLR_E_UNSUPPORTED;
 	}
-	uint32_t blocks_per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
-	blocks_per_cu = std::max<uint32_t>(blocks_per_cu, 1);
-	const uint64_t max_blocks = (uint64_t)p->ctx->n_cus * blocks_per_cu;
-	const uint64_t max_waves = max_blocks * 4;
-	uint64_t us = total_tuples / (max_waves * 4);
+	const uint64_t waves = polr_resident_waves(p, materialize);
+	uint64_t us = (total_tuples + waves - 1) / waves;
 	us = ((us + 63) / 64) * 64;
 	us = std::min<uint64_t>(std::max<uint64_t>(us, 64), 1024);
 	*unit_size = (uint32_t)us;
-	*n_blocks_max = (uint32_t)max_blocks;
+	*n_blocks_max = (uint32_t)(waves / 4);
 	return POLR_OK;
 }
 
@@ -1380,15 +1453,19 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 			HIPCHK(ctx, hipStreamSynchronize(st));
 			hipFree(p->rounds_dev);
 			hipFree(p->prefix_dev);
+			hipFree(p->unit_sizes_dev);
 			p->rounds_dev = nullptr;
 			p->prefix_dev = nullptr;
+			p->unit_sizes_dev = nullptr;
 		}
 		const uint32_t cap = std::max<uint32_t>(n_rounds, 64);
 		HIPCHK(ctx, hipMalloc((void **)&p->rounds_dev, (uint64_t)cap * sizeof(DevRound)));
 		HIPCHK(ctx, hipMalloc((void **)&p->prefix_dev, ((uint64_t)cap + 1) * 8));
+		HIPCHK(ctx, hipMalloc((void **)&p->unit_sizes_dev, (uint64_t)cap * 4));
 		p->rounds_cap = cap;
 	}
 	std::vector<uint64_t> prefix(n_rounds + 1);
+	std::vector<uint32_t> usizes(n_rounds, unit_size);
 	prefix[0] = 0;
 	for (uint32_t r = 0; r < n_rounds; r++) {
 		prefix[r + 1] = prefix[r] + (rounds[r].count + unit_size - 1) / unit_size;
@@ -1397,6 +1474,7 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 	// pageable source: the runtime stages it before returning, so the caller's array may be reused
 	HIPCHK(ctx, hipMemcpyAsync(p->rounds_dev, rounds, (uint64_t)n_rounds * sizeof(DevRound), hipMemcpyHostToDevice, st));
 	HIPCHK(ctx, hipMemcpyAsync(p->prefix_dev, prefix.data(), ((uint64_t)n_rounds + 1) * 8, hipMemcpyHostToDevice, st));
+	HIPCHK(ctx, hipMemcpyAsync(p->unit_sizes_dev, usizes.data(), (uint64_t)n_rounds * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(ctx, hipStreamSynchronize(st)); // prefix is a local vector
 	const uint64_t total_units = prefix[n_rounds];
 	const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(max_blocks, (total_units + 3) / 4);
@@ -1408,7 +1486,7 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 	}
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
 	hipError_t e = polr_launch_path_kernel(dp.W, dp.k, n_blocks, 4, st, materialize ? p->dev_mat : p->dev_count,
-	                                       p->rounds_dev, p->prefix_dev, n_rounds, unit_size, dout,
+	                                       p->rounds_dev, p->prefix_dev, n_rounds, p->unit_sizes_dev, dout,
 	                                       (unsigned long long *)counts_dev);
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));

@@ -55,6 +55,28 @@ struct DevPath {
 	uint32_t order[POLR_KMAX];
 };
 
+// One join of one join order, fully resolved on the host at pipeline creation so the path kernel
+// needs no pointer chasing: which tuple slot indexes the key column(s), where the key column lives,
+// which index to probe and which tuple slot receives the matched build row.
+struct StageDesc {
+	uint32_t kind;
+	uint32_t n_keys;
+	uint32_t key_width[2];
+	uint32_t key_signed;
+	int32_t key_slot[2];        // tuple slot whose value indexes key column c (0 = probe row)
+	int32_t out_slot;           // tuple slot that receives this join's build id, -1: not carried
+	const uint8_t *key_data[2];
+	const uint8_t *key_valid[2];
+	const void *table;
+	const uint32_t *rowids;
+	uint64_t mask;
+	int64_t min_value;
+	uint64_t range;
+	uint32_t sentinel_start;
+	uint32_t sentinel_count;
+};
+#define STAGE_DESC_DWORDS (sizeof(StageDesc) / 4)
+
 struct DevPipeline {
 	uint32_t k;
 	uint32_t n_paths;
@@ -67,6 +89,7 @@ struct DevPipeline {
 	uint64_t n_tuples;
 	DevJoin joins[POLR_KMAX];
 	DevPath paths[POLR_PMAX];
+	const StageDesc *stages; // [n_paths][POLR_KMAX], resolved per (join order, position)
 };
 
 // one routed slice; must match polr_round in include/polr_hip.h

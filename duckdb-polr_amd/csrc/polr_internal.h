@@ -64,9 +64,12 @@ struct polr_pipeline {
 	std::vector<polr_ht *> hts;
 	DevPipeline host_count, host_mat; // count-only (narrow tuples) and materialising (all ids) variants
 	DevPipeline *dev_count = nullptr, *dev_mat = nullptr;
+	StageDesc *stages_count = nullptr, *stages_mat = nullptr; // [n_paths][POLR_KMAX] each
+	int blocks_per_cu_count = 0, blocks_per_cu_mat = 0;       // measured residency of the path kernel
 	// launch scratch (grown on demand)
 	DevRound *rounds_dev = nullptr;
 	uint64_t *prefix_dev = nullptr;
+	uint32_t *unit_sizes_dev = nullptr;
 	uint32_t rounds_cap = 0;
 	unsigned long long *counts_dev = nullptr;
 	uint64_t counts_cap = 0;
@@ -104,10 +107,11 @@ static inline hipStream_t polr_stream(polr_ctx *ctx, void *stream) {
 
 // kernels / launchers implemented in polr_build.hip and polr_probe.hip
 size_t polr_path_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_per_block);
+int polr_path_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block);
 hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
                                    hipStream_t stream, const DevPipeline *pipe, const DevRound *rounds,
-                                   const uint64_t *unit_prefix, uint32_t n_rounds, uint32_t unit_size, DevOut out,
-                                   unsigned long long *counts);
+                                   const uint64_t *unit_prefix, uint32_t n_rounds, const uint32_t *unit_sizes,
+                                   DevOut out, unsigned long long *counts);
 void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,
@@ -132,3 +136,4 @@ void polr_launch_chunk_prefix(hipStream_t st, const uint32_t *chunk_count, uint3
 // shared between capi and mpx
 int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, uint32_t *unit_size,
                      uint32_t *n_blocks_max);
+uint32_t polr_resident_waves(polr_pipeline *p, bool materialize);

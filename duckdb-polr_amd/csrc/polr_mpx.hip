@@ -45,6 +45,7 @@ struct polr_mpx {
 	DevMpx *dev = nullptr;
 	DevRound *round_dev = nullptr;
 	uint64_t *prefix_dev = nullptr;
+	uint32_t *unit_size_dev = nullptr;
 	unsigned long long *counts_dev = nullptr;
 	uint64_t *chunk_offsets_dev = nullptr;
 	uint32_t *log_path = nullptr;
@@ -126,8 +127,8 @@ __global__ void polr_mpx_set_range_kernel(DevMpx *m, uint64_t chunk_begin, uint6
 }
 
 // one routing decision
-__global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *unit_prefix,
-                                       unsigned long long *counts, uint32_t k, uint32_t unit_size) {
+__global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *unit_prefix, uint32_t *unit_size_out,
+                                       unsigned long long *counts, uint32_t k, uint32_t resident_waves) {
 	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487)
 	uint64_t s = 0;
 	for (uint32_t j = 0; j < k; j++) {
@@ -145,6 +146,7 @@ __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *uni
 	round->emit = 0;
 	unit_prefix[0] = 0;
 	unit_prefix[1] = 0;
+	unit_size_out[0] = 64;
 	if (m->chunk_idx >= m->chunk_end) {
 		m->done = 1;
 		return;
@@ -197,7 +199,12 @@ __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *uni
 	round->path = (uint32_t)path;
 	// ALTERNATE forwards only path 0's output (polar_pipeline_executor.cpp:445-447,514-523)
 	round->emit = (core.routing != polr::ALTERNATE || path == 0) ? 1u : 0u;
-	unit_prefix[1] = (tuples + unit_size - 1) / unit_size;
+	// unit size: spread a small round over many waves, give a table-sized round a few units per wave
+	uint64_t us = (tuples + resident_waves - 1) / resident_waves;
+	us = ((us + 63) / 64) * 64;
+	us = us < 64 ? 64 : (us > 1024 ? 1024 : us);
+	unit_size_out[0] = (uint32_t)us;
+	unit_prefix[1] = (tuples + us - 1) / us;
 }
 
 // PushFinalize's closing FinalizePathRun (polar_pipeline_executor.cpp:150-151)
@@ -256,6 +263,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	hipError_t e = hipMalloc((void **)&m->dev, sizeof(DevMpx));
 	e = e == hipSuccess ? hipMalloc((void **)&m->round_dev, sizeof(DevRound)) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->prefix_dev, 2 * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->unit_size_dev, 2 * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
@@ -325,6 +333,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	if (rc) {
 		return rc;
 	}
+	const uint32_t resident_waves = polr_resident_waves(p, materialize);
 	DevOut dout;
 	memset(&dout, 0, sizeof(dout));
 	if (out) {
@@ -339,7 +348,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	for (;;) {
 		for (int i = 0; i < batch; i++) {
 			hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(1), 0, st, m->dev, m->round_dev, m->prefix_dev,
-			                   m->counts_dev, p->k, m->unit_size);
+			                   m->unit_size_dev, m->counts_dev, p->k, resident_waves);
 			size_t ev = 0;
 			if (m->timing) {
 				ev = m->ev_used++;
@@ -353,7 +362,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 				HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
 			}
 			hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
-			                                       m->unit_size, dout, m->counts_dev);
+			                                       m->unit_size_dev, dout, m->counts_dev);
 			if (e != hipSuccess) {
 				POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
 			}
@@ -465,6 +474,9 @@ void polr_mpx_destroy(polr_mpx *m) {
 	}
 	if (m->prefix_dev) {
 		hipFree(m->prefix_dev);
+	}
+	if (m->unit_size_dev) {
+		hipFree(m->unit_size_dev);
 	}
 	if (m->counts_dev) {
 		hipFree(m->counts_dev);
