@@ -1145,6 +1145,9 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	if (p->counts_dev) {
 		hipFree(p->counts_dev);
 	}
+	if (p->shards_dev) {
+		hipFree(p->shards_dev);
+	}
 	delete p;
 }
 
@@ -1438,10 +1441,22 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
-	HIPCHK(ctx, hipMemsetAsync(counts_dev, 0, (uint64_t)n_rounds * p->k * 8, st));
 	if (total == 0) {
+		HIPCHK(ctx, hipMemsetAsync(counts_dev, 0, (uint64_t)n_rounds * p->k * 8, st));
 		return POLR_OK;
 	}
+	const uint64_t need_shards = (uint64_t)n_rounds * POLR_NSHARD * p->k;
+	if (need_shards > p->shards_cap) {
+		if (p->shards_dev) {
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			hipFree(p->shards_dev);
+			p->shards_dev = nullptr;
+		}
+		const uint64_t cap = std::max<uint64_t>(need_shards, 64 * POLR_NSHARD * POLR_KMAX);
+		HIPCHK(ctx, hipMalloc((void **)&p->shards_dev, cap * 8));
+		p->shards_cap = cap;
+	}
+	HIPCHK(ctx, hipMemsetAsync(p->shards_dev, 0, need_shards * 8, st));
 	const bool materialize = out != nullptr;
 	uint32_t unit_size, max_blocks;
 	int rc = polr_plan_launch(p, materialize, total, &unit_size, &max_blocks);
@@ -1487,10 +1502,11 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
 	hipError_t e = polr_launch_path_kernel(dp.W, dp.k, n_blocks, 4, st, materialize ? p->dev_mat : p->dev_count,
 	                                       p->rounds_dev, p->prefix_dev, n_rounds, p->unit_sizes_dev, dout,
-	                                       (unsigned long long *)counts_dev);
+	                                       p->shards_dev);
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
 	}
+	polr_launch_reduce_counts(st, p->shards_dev, n_rounds, p->k, (unsigned long long *)counts_dev);
 	return POLR_OK;
 }
 

@@ -83,6 +83,31 @@ extern "C++" void polr_launch_compact_ids(hipStream_t stream, DevOut out, const 
 	hipLaunchKernelGGL(polr_compact_ids_kernel, dim3(n_chunks), dim3(256), 0, stream, out, chunk_base, n_chunks, dst);
 }
 
+// sum the per-workgroup shards of the round counters: dst[r*k + j] = sum_s src[(r*NSHARD + s)*k + j]
+__global__ void polr_reduce_counts_kernel(const unsigned long long *__restrict__ src, uint64_t n, uint32_t k,
+                                          unsigned long long *__restrict__ dst) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // i = r*k + j
+	if (i >= n) {
+		return;
+	}
+	const uint64_t r = i / k, j = i % k;
+	unsigned long long s = 0;
+	for (uint32_t sh = 0; sh < POLR_NSHARD; sh++) {
+		s += src[(r * POLR_NSHARD + sh) * k + j];
+	}
+	dst[i] = s;
+}
+
+extern "C++" void polr_launch_reduce_counts(hipStream_t stream, const unsigned long long *src, uint64_t n_rounds,
+                                            uint32_t k, unsigned long long *dst) {
+	const uint64_t n = n_rounds * k;
+	if (n == 0) {
+		return;
+	}
+	hipLaunchKernelGGL(polr_reduce_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, k,
+	                   dst);
+}
+
 // ---- path-kernel dispatch over the compiled stage counts ------------------------------------------
 #define DECL_K(KK)                                                                                                     \
 	size_t polr_path_lds_bytes_k##KK(uint32_t W, uint32_t waves_per_block);                                           \

@@ -73,6 +73,8 @@ struct polr_pipeline {
 	uint32_t rounds_cap = 0;
 	unsigned long long *counts_dev = nullptr;
 	uint64_t counts_cap = 0;
+	unsigned long long *shards_dev = nullptr; // [rounds][POLR_NSHARD][k] scratch of the path kernel
+	uint64_t shards_cap = 0;
 };
 
 struct polr_out {
@@ -116,6 +118,8 @@ void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_ba
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,
                              uint32_t *dst);
+void polr_launch_reduce_counts(hipStream_t stream, const unsigned long long *src, uint64_t n_rounds, uint32_t k,
+                               unsigned long long *dst);
 void polr_launch_deserialize_col(hipStream_t st, const uint8_t *rows, uint64_t n_rows, uint32_t row_width, uint32_t col,
                                  uint32_t offset, uint32_t width, uint8_t *dst, uint8_t *dst_valid);
 void polr_launch_s16_build(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows, uint4 *slots,

@@ -129,12 +129,28 @@ __global__ void polr_mpx_set_range_kernel(DevMpx *m, uint64_t chunk_begin, uint6
 // one routing decision
 __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *unit_prefix, uint32_t *unit_size_out,
                                        unsigned long long *counts, uint32_t k, uint32_t resident_waves) {
-	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487)
+	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487).
+	// One wave: lane s sums shard s of the k counters, a shuffle tree adds the shards, lane 0 routes.
 	uint64_t s = 0;
-	for (uint32_t j = 0; j < k; j++) {
-		s += counts[j];
-		m->stage_out[m->last_path][j] += counts[j];
-		counts[j] = 0;
+	{
+		const uint32_t lane = threadIdx.x;
+		for (uint32_t j = 0; j < k; j++) {
+			unsigned long long v = 0;
+			if (lane < POLR_NSHARD) {
+				v = counts[(uint64_t)lane * k + j];
+				counts[(uint64_t)lane * k + j] = 0;
+			}
+			for (int d = 32; d > 0; d >>= 1) {
+				v += __shfl_down(v, d, 64);
+			}
+			if (lane == 0) {
+				s += v;
+				m->stage_out[m->last_path][j] += v;
+			}
+		}
+		if (lane != 0) {
+			return;
+		}
 	}
 	polr::MultiplexerCore &core = m->core;
 	core.AddNumIntermediates(s);
@@ -211,9 +227,12 @@ __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *uni
 __global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, uint32_t k, polr_mpx_stats *stats) {
 	uint64_t s = 0;
 	for (uint32_t j = 0; j < k; j++) {
-		s += counts[j];
-		m->stage_out[m->last_path][j] += counts[j];
-		counts[j] = 0;
+		for (uint32_t sh = 0; sh < POLR_NSHARD; sh++) {
+			const unsigned long long v = counts[(uint64_t)sh * k + j];
+			s += v;
+			m->stage_out[m->last_path][j] += v;
+			counts[(uint64_t)sh * k + j] = 0;
+		}
 	}
 	polr::MultiplexerCore &core = m->core;
 	core.AddNumIntermediates(s);
@@ -264,12 +283,12 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	e = e == hipSuccess ? hipMalloc((void **)&m->round_dev, sizeof(DevRound)) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->prefix_dev, 2 * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->unit_size_dev, 2 * 4) : e;
-	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_inter, max_log * 8) : e;
 	e = e == hipSuccess ? hipHostMalloc((void **)&m->done_host, 64) : e;
-	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8) : e;
 	if (e != hipSuccess) {
 		polr_mpx_destroy(m);
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer allocation failed: %s", hipGetErrorString(e));
@@ -347,7 +366,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	const int batch = 16;
 	for (;;) {
 		for (int i = 0; i < batch; i++) {
-			hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(1), 0, st, m->dev, m->round_dev, m->prefix_dev,
+			hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(64), 0, st, m->dev, m->round_dev, m->prefix_dev,
 			                   m->unit_size_dev, m->counts_dev, p->k, resident_waves);
 			size_t ev = 0;
 			if (m->timing) {
@@ -389,7 +408,7 @@ int polr_mpx_reset(polr_mpx *m, void *stream) {
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
-	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_KMAX * 8, st));
+	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8, st));
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
 	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter);
 	return POLR_OK;

@@ -506,7 +506,8 @@ __device__ __forceinline__ void flush_counts(WaveCtx<W, K> &c, unsigned long lon
 #pragma unroll
 		for (int p = 0; p < K; p++) {
 			if (p < (int)c.k && c.cnt[p]) {
-				atomicAdd(&counts[(uint64_t)round * c.k + p], (unsigned long long)c.cnt[p]);
+				atomicAdd(&counts[((uint64_t)round * POLR_NSHARD + (blockIdx.x % POLR_NSHARD)) * c.k + p],
+				          (unsigned long long)c.cnt[p]);
 			}
 		}
 	}
