@@ -1107,6 +1107,43 @@ int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t 
 	return POLR_OK;
 }
 
+int polr_pipeline_update_probe(polr_pipeline *p, uint32_t col, const void *data, const uint8_t *valid,
+                               uint64_t n_rows) {
+	if (!p || (!data && n_rows)) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = p->ctx;
+	if (col >= p->n_probe_cols || n_rows > p->n_probe_rows) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "update of probe column %u with %llu rows does not fit (%u columns, %llu rows)",
+		          col, (unsigned long long)n_rows, p->n_probe_cols, (unsigned long long)p->n_probe_rows);
+	}
+	OwnedCol &c = p->probe_cols[col];
+	if (!c.owned) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "probe column %u is caller-owned device memory", col);
+	}
+	if (valid && !c.valid) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "probe column %u was created without a validity array", col);
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (n_rows) {
+		HIPCHK(ctx, hipMemcpyAsync(c.data, data, n_rows * c.width, hipMemcpyHostToDevice, ctx->stream));
+		if (c.valid) {
+			if (valid) {
+				HIPCHK(ctx, hipMemcpyAsync(c.valid, valid, n_rows, hipMemcpyHostToDevice, ctx->stream));
+			} else {
+				HIPCHK(ctx, hipMemsetAsync(c.valid, 1, n_rows, ctx->stream));
+			}
+		}
+	}
+	if (!p->sel_dev) {
+		p->n_tuples = n_rows;
+		p->host_mat.n_tuples = n_rows;
+		p->host_count.n_tuples = n_rows;
+	}
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return POLR_OK;
+}
+
 void polr_pipeline_destroy(polr_pipeline *p) {
 	if (!p) {
 		return;

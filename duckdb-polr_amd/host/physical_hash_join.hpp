@@ -1,0 +1,66 @@
+// duckdb-polr_amd/host/physical_hash_join.hpp -- host mirror of the probe side of PhysicalHashJoin
+// (src/include/duckdb/execution/operator/join/physical_hash_join.hpp:24-111,
+//  src/execution/operator/join/physical_hash_join.cpp:484-577,637-681) backed by a device-resident
+// build side.  Same operator interface: GetOperatorState / GetOperatorStateWithBindings /
+// Execute(input chunk -> output chunk) with the reference's result protocol (HAVE_MORE_OUTPUT while a
+// probed chunk still has matches to hand out, then NEED_MORE_INPUT; FINISHED on an empty build side).
+// There is no host probe: Execute goes through the C ABI (include/polr_hip.h) or throws.
+#pragma once
+
+#include "../../include/polr_hip.h"
+#include "polr_host_types.hpp"
+
+namespace duckdb_polr {
+
+// the probe side of a JoinCondition: a BoundReferenceExpression (or CAST of one, which the caller must
+// have materialised) on the probe chunk (joinside.hpp:17-36, polar_config.cpp:75-82)
+struct JoinCondition {
+	idx_t left_index = 0;
+	bool left_is_bound_ref = true;
+};
+
+struct PerfectHashJoinStats {
+	bool is_build_small = false; // plan_comparison_join.cpp:63-133
+	int64_t build_min = 0, build_max = 0;
+};
+
+class PhysicalHashJoin : public PhysicalOperator {
+public:
+	PhysicalHashJoin(polr_ctx *ctx, vector<LogicalType> probe_types, vector<LogicalType> condition_types,
+	                 vector<LogicalType> build_types, vector<JoinCondition> conditions, JoinType join_type,
+	                 idx_t estimated_cardinality, PerfectHashJoinStats perfect_join_stats = PerfectHashJoinStats());
+	~PhysicalHashJoin() override;
+
+	polr_ctx *ctx;
+	JoinType join_type;
+	vector<JoinCondition> conditions;
+	vector<LogicalType> probe_types, condition_types, build_types;
+	vector<idx_t> right_projection_map;
+	PerfectHashJoinStats perfect_join_statistics;
+	idx_t uncertainty_level = 1; // what UncertainCardinalitySelector's plan walk would return
+
+	// ---- sink side, reduced to what the probe needs: hand the build columns over once -------------
+	// (PhysicalHashJoin::Sink/Finalize physical_hash_join.cpp:217-286,337-481 -> HBM residency)
+	void SinkBuildSide(const vector<Vector> &keys, const vector<Vector> &payload, idx_t count);
+	polr_ht *hash_table = nullptr;
+	bool uses_perfect_hash = false;
+	idx_t build_count = 0;
+
+	// ---- operator interface ---------------------------------------------------------------------------
+	unique_ptr<OperatorState> GetOperatorState(ExecutionContext &context) const override;
+	unique_ptr<OperatorState> GetOperatorStateWithBindings(ExecutionContext &context,
+	                                                       std::map<idx_t, idx_t> &bindings) const;
+	OperatorResultType Execute(ExecutionContext &context, DataChunk &input, DataChunk &chunk,
+	                           GlobalOperatorState &gstate, OperatorState &state) const override;
+	bool ParallelOperator() const override {
+		return true;
+	}
+	bool RequiresCache() const override {
+		return true;
+	}
+
+private:
+	unique_ptr<OperatorState> MakeState(const vector<idx_t> &key_columns) const;
+};
+
+} // namespace duckdb_polr

@@ -25,7 +25,7 @@ EXPORTS = [
     "polr_abi_version", "polr_ctx_create", "polr_ctx_destroy", "polr_last_error", "polr_ctx_sync",
     "polr_ht_upload_rows", "polr_ht_upload_columns", "polr_ht_finalize_hash", "polr_ht_finalize_perfect",
     "polr_pht_upload", "polr_ht_destroy", "polr_ht_get_info", "polr_ht_export", "polr_ht_alloc_like",
-    "polr_pipeline_create", "polr_pipeline_set_selection", "polr_pipeline_destroy",
+    "polr_pipeline_create", "polr_pipeline_set_selection", "polr_pipeline_update_probe", "polr_pipeline_destroy",
     "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
@@ -102,6 +102,7 @@ def load():
     L.polr_ht_alloc_like.argtypes = [vp, vp, u64, P(vp)]
     L.polr_pipeline_create.argtypes = [vp, P(Col), u32, u64, P(JoinDesc), u32, vp, u32, P(vp)]
     L.polr_pipeline_set_selection.argtypes = [vp, vp, u64, u32]
+    L.polr_pipeline_update_probe.argtypes = [vp, u32, vp, vp, u64]
     L.polr_pipeline_destroy.argtypes = [vp]
     L.polr_pipeline_destroy.restype = None
     L.polr_out_create.argtypes = [vp, u32, u64, P(vp)]

@@ -156,6 +156,12 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
  * chunks (DICTIONARY/sliced vectors, vector.hpp:36-140): sel[i] = probe-table row.  NULL resets
  * to "all rows".  flags: POLR_COL_DEVICE if sel is a device pointer. */
 int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t n_sel, uint32_t flags);
+/* Refresh the cells of probe column `col` in place (a new DataChunk arriving at the operator-level
+ * drop-in, PhysicalHashJoin::Execute physical_hash_join.cpp:637-681): n_rows <= the row count the
+ * pipeline was created with; becomes the new tuple count.  Only for columns the library owns (created
+ * from host pointers). */
+int polr_pipeline_update_probe(polr_pipeline *p, uint32_t col, const void *data, const uint8_t *valid,
+                               uint64_t n_rows);
 void polr_pipeline_destroy(polr_pipeline *p);
 
 /* ---------------------------------------------------------------------------------------------
