@@ -175,12 +175,14 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from polr_amd import capi, workloads
+    from polr_amd import dist as pdist
     ctx = capi.Context(local_rank)  # raises without the HIP library / a gfx950 device: no fallback
     V = args.chunk_size
 
     # ---- workload: same build sides everywhere, one probe partition per rank (weak scaling) -------
     wl0 = build_workload(args.workload, args.scale, workloads.SEED)
-    wl = wl0 if rank == 0 else build_workload(args.workload, args.scale, workloads.SEED + 7919 * rank)
+    wl = wl0 if rank == 0 else build_workload(args.workload, args.scale,
+                                              pdist.probe_partition_seed(workloads.SEED, rank))
     k = len(wl0["joins"])
     paths = workloads.default_paths(k, "each_last_once")
 
@@ -196,25 +198,21 @@ def main():
     bcast_bytes = 0
     if world > 1:
         new_joins = []
+
+        def wrap(buf):
+            return torch.as_tensor(_DevBuf(buf[0], buf[1]), device=dev)
+
         for x in range(k):
-            if rank == 0:
-                meta, bufs = joins[x][0].export()
-                meta_t = torch.tensor(list(meta), dtype=torch.uint8, device=dev)
-                n_meta = torch.tensor([len(meta)], dtype=torch.int64, device=dev)
-            else:
-                n_meta = torch.zeros(1, dtype=torch.int64, device=dev)
-            dist.broadcast(n_meta, 0)
+            exported = joins[x][0].export() if rank == 0 else None
+
+            def alloc_like(meta):
+                ht = capi.HashTable.alloc_like(ctx, meta)
+                return ht, ht.export()[1]
+
+            ht, nbytes = pdist.broadcast_table(dist, torch, dev, rank, exported, alloc_like, wrap)
+            bcast_bytes += nbytes
             if rank != 0:
-                meta_t = torch.zeros(int(n_meta.item()), dtype=torch.uint8, device=dev)
-            dist.broadcast(meta_t, 0)
-            if rank != 0:
-                ht = capi.HashTable.alloc_like(ctx, bytes(meta_t.cpu().numpy().tobytes()))
-                _m, bufs = ht.export()
                 new_joins.append((ht, wl0["joins"][x]["key_src"]))
-            for ptr, nbytes in bufs:
-                t = torch.as_tensor(_DevBuf(ptr, nbytes), device=dev)
-                dist.broadcast(t, 0)
-                bcast_bytes += nbytes
         if rank != 0:
             joins = new_joins
         torch.cuda.synchronize()
@@ -272,16 +270,9 @@ def main():
     kernel_ms, launches = mpx.kernel_time()
     mpx.enable_timing(False)
 
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tup_t = torch.tensor([float(n_tuples)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tup_t, op=dist.ReduceOp.SUM)
-    dt_max = float(dt_t.item())
-    total_tuples = float(tup_t.item())
+    value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, n_tuples, dt, args.steps)
 
     if rank == 0:
-        value = total_tuples * args.steps / dt_max
         alg = algorithmic_bytes(wl, joins_info, paths.tolist(), st["input_tuple_count_per_path"], st["stage_out"])
         roof = None
         if launches:
