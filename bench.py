@@ -155,6 +155,11 @@ def main():
     ap.add_argument("--regret-budget", type=float, default=0.01)
     ap.add_argument("--init-tuple-count", type=int, default=1024)
     ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
+    ap.add_argument("--executors", type=int, default=8,
+                    help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
+                         "contiguous share of the source chunks on its own HIP stream -- the counterpart of the "
+                         "reference's worker threads (one PipelineExecutor + MultiplexerState per thread, "
+                         "pipeline.cpp:145-174); 1 = the single-executor trace the parity tests pin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -237,38 +242,73 @@ def main():
     budget = args.regret_budget
     if args.routing == "exponential_backoff":
         budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
-    mpx = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
-                                 init_tuple_count=args.init_tuple_count, log_rounds=False)
     offs = chunk_offsets_for(sel, n_rows, V)
-    if offs is not None:
-        mpx.set_chunk_offsets(offs)
-        n_chunks = len(offs) - 1
-    else:
-        n_chunks = (n_tuples + V - 1) // V
-    stream = torch.cuda.current_stream().cuda_stream
+    n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
+    E = max(1, min(args.executors, n_chunks))
+    import threading
+    execs = []
+    for e in range(E):
+        m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
+                                   init_tuple_count=args.init_tuple_count, log_rounds=False)
+        if offs is not None:
+            m.set_chunk_offsets(offs)
+        st_e = torch.cuda.Stream(device=dev)
+        execs.append((m, st_e, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
+    results = [None] * E
+
+    def run_executor(e):
+        m, st_e, c0, c1 = execs[e]
+        m.reset(st_e.cuda_stream)
+        m.run(c0, c1, stream=st_e.cuda_stream)
+        results[e] = m.finish(st_e.cuda_stream)
 
     def step():
-        mpx.reset(stream)
-        mpx.run(0, n_chunks, stream=stream)
-        return mpx.finish(stream)
+        if E == 1:
+            run_executor(0)
+        else:
+            ts = [threading.Thread(target=run_executor, args=(e,)) for e in range(E)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        return results
+
+    def merged(res):
+        out = {"num_intermediates": 0, "num_rounds": 0,
+               "input_tuple_count_per_path": [0] * len(paths),
+               "stage_out": [[0] * k for _ in range(len(paths))]}
+        for r in res:
+            out["num_intermediates"] += r["num_intermediates"]
+            out["num_rounds"] += r["num_rounds"]
+            for p in range(len(paths)):
+                out["input_tuple_count_per_path"][p] += r["input_tuple_count_per_path"][p]
+                for j in range(k):
+                    out["stage_out"][p][j] += r["stage_out"][p][j]
+        return out
 
     for _ in range(args.warmup):
-        st = step()
-    mpx.kernel_time()
-    if not args.no_kernel_events:
-        mpx.enable_timing(True)
+        step()
+    for m, _s, _a, _b in execs:
+        m.kernel_time()
+        if not args.no_kernel_events:
+            m.enable_timing(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = step()
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kernel_ms, launches = mpx.kernel_time()
-    mpx.enable_timing(False)
+    st = merged(results)
+    kernel_ms, launches = 0.0, 0
+    for m, _s, _a, _b in execs:
+        ms_e, n_e = m.kernel_time()
+        kernel_ms += ms_e
+        launches += n_e
+        m.enable_timing(False)
 
     value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, n_tuples, dt, args.steps)
 
@@ -308,7 +348,7 @@ def main():
                                     joins_info[1]["n_rows"]) if args.workload == "job_light_01" else args.workload,
                        "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
-                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples},
+                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E},
             "total_intermediates": int(st["num_intermediates"]),
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],

@@ -908,6 +908,7 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 			d.range = dj.range;
 			d.sentinel_start = dj.sentinel_start;
 			d.sentinel_count = dj.sentinel_count;
+			d.unique = (ht->kind == KIND_PERFECT || ht->kind == KIND_S8 || ht->max_run <= 1) ? 1u : 0u;
 		}
 	}
 }
@@ -1447,7 +1448,7 @@ int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, 
 	const uint64_t waves = polr_resident_waves(p, materialize);
 	uint64_t us = (total_tuples + waves - 1) / waves;
 	us = ((us + 63) / 64) * 64;
-	us = std::min<uint64_t>(std::max<uint64_t>(us, 64), 1024);
+	us = std::min<uint64_t>(std::max<uint64_t>(us, 64), 2048);
 	*unit_size = (uint32_t)us;
 	*n_blocks_max = (uint32_t)(waves / 4);
 	return POLR_OK;
@@ -1539,7 +1540,7 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
 	hipError_t e = polr_launch_path_kernel(dp.W, dp.k, n_blocks, 4, st, materialize ? p->dev_mat : p->dev_count,
 	                                       p->rounds_dev, p->prefix_dev, n_rounds, p->unit_sizes_dev, dout,
-	                                       p->shards_dev);
+	                                       p->shards_dev, SelfRoute {});
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
 	}

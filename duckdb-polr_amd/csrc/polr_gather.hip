@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "polr_device.h"
+#include "polr_mpx_device.h"
 
 // ---- output materialisation --------------------------------------------------------------------
 // One thread per output row of every chunk: dst[row] = src[ids[slot][pos]] (RowOperations::Gather,
@@ -115,7 +116,8 @@ extern "C++" void polr_launch_reduce_counts(hipStream_t stream, const unsigned l
 	hipError_t polr_launch_path_kernel_k##KK(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,                 \
 	                                         hipStream_t stream, const DevPipeline *pipe, const DevRound *rounds,    \
 	                                         const uint64_t *unit_prefix, uint32_t n_rounds,                         \
-	                                         const uint32_t *unit_sizes, DevOut out, unsigned long long *counts);
+	                                         const uint32_t *unit_sizes, DevOut out, unsigned long long *counts,    \
+	                                         SelfRoute sr);
 DECL_K(2)
 DECL_K(4)
 DECL_K(8)
@@ -149,16 +151,17 @@ extern "C++" int polr_path_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_
 extern "C++" hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
                                                 hipStream_t stream, const DevPipeline *pipe, const DevRound *rounds,
                                                 const uint64_t *unit_prefix, uint32_t n_rounds,
-                                                const uint32_t *unit_sizes, DevOut out, unsigned long long *counts) {
+                                                const uint32_t *unit_sizes, DevOut out, unsigned long long *counts,
+                                                SelfRoute sr) {
 	switch (compiled_k(k)) {
 	case 2:
 		return polr_launch_path_kernel_k2(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
-		                                  unit_sizes, out, counts);
+		                                  unit_sizes, out, counts, sr);
 	case 4:
 		return polr_launch_path_kernel_k4(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
-		                                  unit_sizes, out, counts);
+		                                  unit_sizes, out, counts, sr);
 	default:
 		return polr_launch_path_kernel_k8(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
-		                                  unit_sizes, out, counts);
+		                                  unit_sizes, out, counts, sr);
 	}
 }

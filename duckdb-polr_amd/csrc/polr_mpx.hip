@@ -13,31 +13,14 @@
 // so a whole morsel is routed with zero host round trips; the host only polls a `done` word once per
 // batch of launches.  Output row sets and per-round intermediates equal the host classes' exactly:
 // same code (polr_routing.h), same IEEE double arithmetic.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <vector>
 
 #include "polr_internal.h"
-#include "polr_routing.h"
-
-struct DevMpx {
-	polr::MultiplexerCore core;
-	uint64_t chunk_idx, chunk_end;
-	uint64_t n_tuples, n_chunks;
-	uint32_t chunk_size;
-	uint32_t done;
-	const uint64_t *chunk_offsets; // nullptr: fixed chunk_size chunks
-	uint64_t num_intermediates_total;
-	uint64_t num_rounds;
-	uint32_t log_enabled, pad;
-	uint64_t max_log, n_log;
-	uint32_t *log_path;
-	uint64_t *log_tuples;
-	uint64_t *log_inter;
-	uint64_t last_path; // path of the round whose counters are still to be absorbed
-	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
-};
+#include "polr_mpx_device.h"
 
 struct polr_mpx {
 	polr_pipeline *pipe = nullptr;
@@ -46,12 +29,18 @@ struct polr_mpx {
 	DevRound *round_dev = nullptr;
 	uint64_t *prefix_dev = nullptr;
 	uint32_t *unit_size_dev = nullptr;
+	uint32_t *ticket_dev = nullptr;
+	polr_mpx_stats *stats_dev = nullptr;
+	unsigned long long *stamps_dev = nullptr; // diagnostic builds only
+	uint32_t iter = 0; // launches of the path kernel so far (descriptor slot = iter & 1)
 	unsigned long long *counts_dev = nullptr;
 	uint64_t *chunk_offsets_dev = nullptr;
 	uint32_t *log_path = nullptr;
 	uint64_t *log_tuples = nullptr, *log_inter = nullptr;
 	uint32_t *done_host = nullptr; // pinned
 	uint32_t unit_size = 256;
+	int poll_batch = 8;
+	uint32_t wide0_mask = 0;
 	uint64_t n_chunks = 0;
 	// optional per-launch timing (measurement only)
 	bool timing = false;
@@ -72,27 +61,11 @@ static void drain_events(polr_mpx *m) {
 	m->ev_used = 0;
 }
 
-__device__ __forceinline__ uint64_t chunk_start(const DevMpx *m, uint64_t c) {
-	if (m->chunk_offsets) {
-		return m->chunk_offsets[c];
-	}
-	const uint64_t s = c * (uint64_t)m->chunk_size;
-	return s < m->n_tuples ? s : m->n_tuples;
-}
-
-__device__ __forceinline__ void log_round(DevMpx *m, uint64_t path, uint64_t tuples, uint64_t inter) {
-	m->num_rounds++;
-	if (m->log_enabled && m->n_log < m->max_log) {
-		m->log_path[m->n_log] = (uint32_t)path;
-		m->log_tuples[m->n_log] = tuples;
-		m->log_inter[m->n_log] = inter;
-		m->n_log++;
-	}
-}
-
 __global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_paths, uint64_t n_tuples,
                                      uint64_t n_chunks, uint32_t *log_path, uint64_t *log_tuples,
-                                     uint64_t *log_inter) {
+                                     uint64_t *log_inter, uint32_t wide0_mask) {
+	m->wide0_mask = wide0_mask;
+	m->pad2 = 0;
 	m->core.Init(cfg.routing, n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
 	m->chunk_idx = m->chunk_end = 0;
 	m->n_tuples = n_tuples;
@@ -114,6 +87,7 @@ __global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_
 			m->stage_out[p][j] = 0;
 		}
 	}
+	// (one thread: runs once per pass, ~300 stores)
 }
 
 __global__ void polr_mpx_set_range_kernel(DevMpx *m, uint64_t chunk_begin, uint64_t chunk_end,
@@ -126,133 +100,53 @@ __global__ void polr_mpx_set_range_kernel(DevMpx *m, uint64_t chunk_begin, uint6
 	m->done = chunk_begin >= chunk_end ? 1 : 0;
 }
 
-// one routing decision
+// stand-alone routing step: primes the first round of a run (later rounds are routed by the last
+// workgroup of each path-kernel launch)
 __global__ void polr_mpx_router_kernel(DevMpx *m, DevRound *round, uint64_t *unit_prefix, uint32_t *unit_size_out,
                                        unsigned long long *counts, uint32_t k, uint32_t resident_waves) {
-	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487).
-	// One wave: lane s sums shard s of the k counters, a shuffle tree adds the shards, lane 0 routes.
-	uint64_t s = 0;
-	{
-		const uint32_t lane = threadIdx.x;
-		for (uint32_t j = 0; j < k; j++) {
-			unsigned long long v = 0;
-			if (lane < POLR_NSHARD) {
-				v = counts[(uint64_t)lane * k + j];
-				counts[(uint64_t)lane * k + j] = 0;
-			}
-			for (int d = 32; d > 0; d >>= 1) {
-				v += __shfl_down(v, d, 64);
-			}
-			if (lane == 0) {
-				s += v;
-				m->stage_out[m->last_path][j] += v;
-			}
-		}
-		if (lane != 0) {
-			return;
-		}
-	}
-	polr::MultiplexerCore &core = m->core;
-	core.AddNumIntermediates(s);
-	m->num_intermediates_total += s;
-
-	round->begin = 0;
-	round->count = 0;
-	round->path = 0;
-	round->emit = 0;
-	unit_prefix[0] = 0;
-	unit_prefix[1] = 0;
-	unit_size_out[0] = 64;
-	if (m->chunk_idx >= m->chunk_end) {
-		m->done = 1;
-		return;
-	}
-	uint64_t begin, tuples, path;
-	if (core.num_cache_flushing_skips > 0) {
-		// the window continues (a previous run() ended inside it): whole chunks bypass routing
-		const uint64_t left = m->chunk_end - m->chunk_idx;
-		const uint64_t n = core.num_cache_flushing_skips < left ? core.num_cache_flushing_skips : left;
-		begin = chunk_start(m, m->chunk_idx);
-		tuples = chunk_start(m, m->chunk_idx + n) - begin;
-		core.IncreaseInputTupleCount(tuples);
-		if (core.num_cache_flushing_skips != polr::kIdxMax) {
-			core.num_cache_flushing_skips -= n;
-		}
-		m->chunk_idx += n;
-		path = core.current_path_idx;
-	} else {
-		const uint64_t c0 = chunk_start(m, m->chunk_idx);
-		const uint64_t size = chunk_start(m, m->chunk_idx + 1) - c0;
-		const uint64_t prev_path = core.current_path_idx;
-		const uint64_t prev_tuples = core.current_path_tuple_count;
-		bool finalized;
-		uint64_t closed = 0;
-		const polr::RouteDecision d = core.Execute(size, &finalized, &closed);
-		if (finalized) {
-			log_round(m, prev_path, prev_tuples, closed);
-		}
-		begin = c0 + d.offset;
-		tuples = d.count;
-		path = d.path;
-		if (!d.have_more_output) {
-			m->chunk_idx++;
-			if (core.num_cache_flushing_skips > 0 && m->chunk_idx < m->chunk_end) {
-				const uint64_t left = m->chunk_end - m->chunk_idx;
-				const uint64_t n = core.num_cache_flushing_skips < left ? core.num_cache_flushing_skips : left;
-				const uint64_t extra = chunk_start(m, m->chunk_idx + n) - chunk_start(m, m->chunk_idx);
-				core.IncreaseInputTupleCount(extra);
-				if (core.num_cache_flushing_skips != polr::kIdxMax) {
-					core.num_cache_flushing_skips -= n;
-				}
-				m->chunk_idx += n;
-				tuples += extra;
-			}
-		}
-	}
-	m->last_path = path;
-	round->begin = begin;
-	round->count = tuples;
-	round->path = (uint32_t)path;
-	// ALTERNATE forwards only path 0's output (polar_pipeline_executor.cpp:445-447,514-523)
-	round->emit = (core.routing != polr::ALTERNATE || path == 0) ? 1u : 0u;
-	// unit size: spread a small round over many waves, give a table-sized round a few units per wave
-	uint64_t us = (tuples + resident_waves - 1) / resident_waves;
-	us = ((us + 63) / 64) * 64;
-	us = us < 64 ? 64 : (us > 1024 ? 1024 : us);
-	unit_size_out[0] = (uint32_t)us;
-	unit_prefix[1] = (tuples + us - 1) / us;
+	polr_router_step(m, round, unit_prefix, unit_size_out, counts, k, resident_waves, threadIdx.x, false, nullptr);
 }
 
-// PushFinalize's closing FinalizePathRun (polar_pipeline_executor.cpp:150-151)
+// PushFinalize's closing FinalizePathRun (polar_pipeline_executor.cpp:150-151); one wave
 __global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, uint32_t k, polr_mpx_stats *stats) {
+	const uint32_t lane = threadIdx.x;
+	polr::MultiplexerCore &core = m->core;
 	uint64_t s = 0;
 	for (uint32_t j = 0; j < k; j++) {
-		for (uint32_t sh = 0; sh < POLR_NSHARD; sh++) {
-			const unsigned long long v = counts[(uint64_t)sh * k + j];
+		unsigned long long v = 0;
+		if (lane < POLR_NSHARD) {
+			v = counts[(uint64_t)lane * k + j];
+			counts[(uint64_t)lane * k + j] = 0;
+		}
+		for (int d = 32; d > 0; d >>= 1) {
+			v += __shfl_down(v, d, 64);
+		}
+		if (lane == 0) {
 			s += v;
 			m->stage_out[m->last_path][j] += v;
-			counts[(uint64_t)sh * k + j] = 0;
 		}
 	}
-	polr::MultiplexerCore &core = m->core;
-	core.AddNumIntermediates(s);
-	m->num_intermediates_total += s;
-	if (!core.first_mpx_run) {
-		const uint64_t path = core.current_path_idx, tuples = core.current_path_tuple_count;
-		const uint64_t closed = core.FinalizePathRun();
-		log_round(m, path, tuples, closed);
-		// a finalized run must not be finalized twice if the caller keeps routing afterwards
-		core.current_path_tuple_count = 0;
+	if (lane == 0) {
+		core.AddNumIntermediates(s);
+		m->num_intermediates_total += s;
+		if (!core.first_mpx_run) {
+			const uint64_t path = core.current_path_idx, tuples = core.current_path_tuple_count;
+			const uint64_t closed = core.FinalizePathRun();
+			log_round(m, path, tuples, closed);
+			// a finalized run must not be finalized twice if the caller keeps routing afterwards
+			core.current_path_tuple_count = 0;
+		}
+		stats->num_tuples_processed = core.num_tuples_processed;
+		stats->num_intermediates = m->num_intermediates_total;
+		stats->num_rounds = m->num_rounds;
 	}
-	stats->num_tuples_processed = core.num_tuples_processed;
-	stats->num_intermediates = m->num_intermediates_total;
-	stats->num_rounds = m->num_rounds;
-	for (uint32_t i = 0; i < POLR_MAX_PATHS; i++) {
+	__syncthreads();
+	for (uint32_t i = lane; i < POLR_MAX_PATHS; i += 64) {
 		stats->input_tuple_count_per_path[i] = i < core.path_count ? core.input_tuple_count_per_path[i] : 0;
 		stats->path_resistances[i] = i < core.path_count ? core.path_resistances[i] : 0;
-		for (uint32_t j = 0; j < POLR_MAX_JOINS; j++) {
-			stats->stage_out[i][j] = m->stage_out[i][j];
-		}
+	}
+	for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
+		stats->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = m->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS];
 	}
 }
 
@@ -280,9 +174,11 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	m->n_chunks = (p->n_tuples + cfg->chunk_size - 1) / cfg->chunk_size;
 	const uint64_t max_log = cfg->log_rounds ? std::max<uint64_t>(cfg->max_log_rounds, 1) : 1;
 	hipError_t e = hipMalloc((void **)&m->dev, sizeof(DevMpx));
-	e = e == hipSuccess ? hipMalloc((void **)&m->round_dev, sizeof(DevRound)) : e;
-	e = e == hipSuccess ? hipMalloc((void **)&m->prefix_dev, 2 * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->round_dev, 2 * sizeof(DevRound)) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->prefix_dev, 4 * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->unit_size_dev, 2 * 4) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->ticket_dev, 64) : e;
+	e = e == hipSuccess ? hipMemset(m->ticket_dev, 0, 64) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
@@ -294,8 +190,14 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer allocation failed: %s", hipGetErrorString(e));
 	}
 	m->cfg.max_log_rounds = (uint32_t)max_log;
+	for (uint32_t q = 0; q < p->n_paths; q++) {
+		const polr_ht *ht0 = p->hts[p->host_count.paths[q].order[0]];
+		if (ht0->kind == KIND_PERFECT || ht0->kind == KIND_S8 || ht0->max_run <= 1) {
+			m->wide0_mask |= 1u << q;
+		}
+	}
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, ctx->stream, m->dev, m->cfg, p->n_paths, p->n_tuples,
-	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter);
+	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask);
 	e = hipStreamSynchronize(ctx->stream);
 	if (e != hipSuccess) {
 		polr_mpx_destroy(m);
@@ -352,7 +254,19 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	if (rc) {
 		return rc;
 	}
-	const uint32_t resident_waves = polr_resident_waves(p, materialize);
+#ifdef POLR_DIAG_STAMPS
+	if (!m->stamps_dev) {
+		HIPCHK(ctx, hipMalloc((void **)&m->stamps_dev, 4096 * 8 * 8));
+		HIPCHK(ctx, hipMemset(m->stamps_dev, 0, 4096 * 8 * 8));
+	}
+#endif
+	uint32_t resident_waves = polr_resident_waves(p, materialize);
+	if (const char *e = getenv("POLR_EXP_WAVES")) { // experiment knob: pretend fewer resident waves (bigger units)
+		resident_waves = (uint32_t)atoi(e);
+	}
+	if (const char *e = getenv("POLR_EXP_BLOCKS")) {
+		max_blocks = (uint32_t)atoi(e);
+	}
 	DevOut dout;
 	memset(&dout, 0, sizeof(dout));
 	if (out) {
@@ -363,11 +277,23 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	const DevPipeline *dpd = materialize ? p->dev_mat : p->dev_count;
 	hipLaunchKernelGGL(polr_mpx_set_range_kernel, dim3(1), dim3(1), 0, st, m->dev, chunk_begin, chunk_end,
 	                   (const uint64_t *)m->chunk_offsets_dev, m->n_chunks, p->n_tuples);
-	const int batch = 16;
+	// prime: route the first round of this run into the descriptor slot the next launch reads
+	const uint32_t slot0 = m->iter & 1u;
+	hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(64), 0, st, m->dev, m->round_dev + slot0,
+	                   m->prefix_dev + 2 * slot0, m->unit_size_dev + slot0, m->counts_dev, p->k, resident_waves);
+	SelfRoute sr;
+	sr.mpx = m->dev;
+	sr.rounds_base = m->round_dev;
+	sr.prefix_base = m->prefix_dev;
+	sr.unit_base = m->unit_size_dev;
+	sr.ticket = m->ticket_dev;
+	sr.resident_waves = resident_waves;
+	sr.stamps = m->stamps_dev;
+	// every launch probes the round in its slot and its last workgroup routes the next one; the host only
+	// polls `done` once per batch of launches (launches after the end find an empty round and exit)
+	const int batch = m->poll_batch;
 	for (;;) {
 		for (int i = 0; i < batch; i++) {
-			hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(64), 0, st, m->dev, m->round_dev, m->prefix_dev,
-			                   m->unit_size_dev, m->counts_dev, p->k, resident_waves);
 			size_t ev = 0;
 			if (m->timing) {
 				ev = m->ev_used++;
@@ -380,8 +306,9 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 				}
 				HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
 			}
+			sr.iter = m->iter++;
 			hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
-			                                       m->unit_size_dev, dout, m->counts_dev);
+			                                       m->unit_size_dev, dout, m->counts_dev, sr);
 			if (e != hipSuccess) {
 				POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
 			}
@@ -410,9 +337,16 @@ int polr_mpx_reset(polr_mpx *m, void *stream) {
 	hipStream_t st = polr_stream(ctx, stream);
 	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8, st));
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
-	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter);
+	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask);
 	return POLR_OK;
 }
+
+#ifdef POLR_DIAG_STAMPS
+// diagnostic: dump the stamps of the first `n` launches (100 MHz ticks)
+extern "C" int polr_mpx_dump_stamps(polr_mpx *m, unsigned long long *dst, uint32_t n) {
+	return hipMemcpy(dst, m->stamps_dev, (size_t)n * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int polr_mpx_enable_timing(polr_mpx *m, int enable) {
 	if (!m) {
@@ -440,12 +374,13 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
-	polr_mpx_stats *sd = nullptr;
-	HIPCHK(ctx, hipMalloc((void **)&sd, sizeof(polr_mpx_stats)));
-	hipLaunchKernelGGL(polr_mpx_finish_kernel, dim3(1), dim3(1), 0, st, m->dev, m->counts_dev, m->pipe->k, sd);
-	hipError_t e = hipMemcpyAsync(stats, sd, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st);
+	if (!m->stats_dev) {
+		HIPCHK(ctx, hipMalloc((void **)&m->stats_dev, sizeof(polr_mpx_stats)));
+	}
+	hipLaunchKernelGGL(polr_mpx_finish_kernel, dim3(1), dim3(64), 0, st, m->dev, m->counts_dev, m->pipe->k,
+	                   m->stats_dev);
+	hipError_t e = hipMemcpyAsync(stats, m->stats_dev, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st);
 	e = e == hipSuccess ? hipStreamSynchronize(st) : e;
-	hipFree(sd);
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer finish failed: %s", hipGetErrorString(e));
 	}
@@ -496,6 +431,12 @@ void polr_mpx_destroy(polr_mpx *m) {
 	}
 	if (m->unit_size_dev) {
 		hipFree(m->unit_size_dev);
+	}
+	if (m->ticket_dev) {
+		hipFree(m->ticket_dev);
+	}
+	if (m->stats_dev) {
+		hipFree(m->stats_dev);
 	}
 	if (m->counts_dev) {
 		hipFree(m->counts_dev);

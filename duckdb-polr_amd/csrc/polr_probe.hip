@@ -26,15 +26,44 @@
 // the per-(join order, position) descriptors are pre-resolved on the host (StageDesc), staged in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 #include "polr_device.h"
+#include "polr_mpx_device.h"
 
 #ifndef POLR_K
 #error "compile with -DPOLR_K=<compiled stage count>"
 #endif
 
-#define QCAP 128 // per-stage queue capacity in tuples: 63 residual + one batch of 64
+// Per-stage input queues (LDS, per wave).  Stage 1 is fed by the wide stage-0 step (up to 256 matches at
+// once): capacity 63 residual + 256; deeper queues take one batch of 64 at a time: 63 + 64.
+#define QCAP1 320
+#define QCAPN 128
+#define WIDE 4 // tuples per lane of a wide stage-0 step
+template <int POS>
+__device__ __host__ constexpr int qcap() {
+	return POS == 1 ? QCAP1 : QCAPN;
+}
+template <int W, int POS>
+__device__ __host__ constexpr int qoff() { // dword offset of the queue that feeds stage POS (POS >= 1)
+	return POS <= 1 ? 0 : W * QCAP1 + (POS - 2) * W * QCAPN;
+}
+template <int W, int K>
+__device__ __host__ constexpr int qtotal() {
+	return K <= 1 ? 0 : W * QCAP1 + (K - 2) * W * QCAPN;
+}
 #define NO_CHUNK 0xFFFFFFFFu
+
+// diagnostic build only (-DPOLR_DIAG_STAMPS): wall-clock stamps of workgroup 0 / wave 0 at the phase
+// boundaries of a self-routing launch, written to sr.stamps[iter*8 + i] (never compiled into the product)
+#ifdef POLR_DIAG_STAMPS
+#define STAMP(i)                                                                                                       \
+	if (sr.stamps && blockIdx.x == 0 && threadIdx.x == 0) {                                                            \
+		sr.stamps[(uint64_t)sr.iter * 8 + (i)] = wall_clock64();                                                       \
+	}
+#else
+#define STAMP(i)
+#endif
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
 	return __builtin_amdgcn_readfirstlane(v);
@@ -166,26 +195,58 @@ __device__ __forceinline__ bool lookup_perfect(const Stage &s, uint64_t key, boo
 	return hit;
 }
 
-__device__ __forceinline__ bool lookup_s8(const Stage &s, uint64_t key, bool valid, uint32_t &id) {
-	const uint2 *tab = (const uint2 *)s.table;
-	const uint32_t k32 = (uint32_t)key;
-	uint64_t slot = polr_murmurhash64((uint64_t)k32) & s.mask;
-	bool hit = false;
-	bool searching = valid;
-	id = 0;
-	while (searching) {
-		const uint2 e = tab[slot];
-		if (e.y == S8_EMPTY_ROW) {
-			searching = false;
-		} else if (e.x == k32) {
-			hit = true;
-			id = e.y;
-			searching = false;
-		} else {
-			slot = (slot + 1) & s.mask;
+// Linear probing, but one round trip inspects an aligned group of slots (32 bytes): a wave waits for its
+// slowest lane, so what counts is the number of DEPENDENT loads of the unluckiest of 64 lanes; at load
+// factor <= 0.5 a group of 4 (2) slots almost always holds the end of the probe sequence.
+struct S8Probe { // one in-flight {key,row} probe
+	uint64_t group;
+	uint32_t first;
+	uint32_t k32;
+	bool searching;
+	bool hit;
+	uint32_t id;
+};
+
+__device__ __forceinline__ void s8_begin(const Stage &s, uint64_t key, bool valid, S8Probe &p) {
+	p.k32 = (uint32_t)key;
+	const uint64_t h = polr_murmurhash64((uint64_t)p.k32) & s.mask;
+	p.group = h >> 2;
+	p.first = (uint32_t)(h & 3);
+	p.searching = valid;
+	p.hit = false;
+	p.id = 0;
+}
+
+__device__ __forceinline__ void s8_check(const Stage &s, S8Probe &p, const uint4 a, const uint4 b) {
+	const uint32_t kk[4] = {a.x, a.z, b.x, b.z};
+	const uint32_t rr[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		if (p.searching && (uint32_t)i >= p.first) {
+			if (rr[i] == S8_EMPTY_ROW) {
+				p.searching = false;
+			} else if (kk[i] == p.k32) {
+				p.hit = true;
+				p.id = rr[i];
+				p.searching = false;
+			}
 		}
 	}
-	return hit;
+	p.first = 0;
+	p.group = (p.group + 1) & (s.mask >> 2);
+}
+
+__device__ __forceinline__ bool lookup_s8(const Stage &s, uint64_t key, bool valid, uint32_t &id) {
+	const uint4 *tab = (const uint4 *)s.table; // 2 slots {key,row} per uint4
+	S8Probe p;
+	s8_begin(s, key, valid, p);
+	while (p.searching) {
+		const uint4 a = tab[p.group * 2];
+		const uint4 b = tab[p.group * 2 + 1];
+		s8_check(s, p, a, b);
+	}
+	id = p.id;
+	return p.hit;
 }
 
 __device__ __forceinline__ void lookup_s16(const Stage &s, uint64_t key, bool valid, uint32_t &start,
@@ -201,19 +262,35 @@ __device__ __forceinline__ void lookup_s16(const Stage &s, uint64_t key, bool va
 		count = s.sentinel_count;
 		return;
 	}
-	uint64_t slot = polr_murmurhash64(key) & s.mask;
+	const uint64_t h = polr_murmurhash64(key) & s.mask;
+	uint64_t group = h >> 1; // 2 slots per group
+	uint32_t first = (uint32_t)(h & 1);
+	const uint64_t gmask = s.mask >> 1;
 	while (true) {
-		const uint4 e = tab[slot];
-		const uint64_t ek = ((uint64_t)e.y << 32) | e.x;
-		if (ek == S16_EMPTY_KEY) {
+		const uint4 e0 = tab[group * 2];
+		const uint4 e1 = tab[group * 2 + 1];
+		if (first == 0) {
+			const uint64_t k0 = ((uint64_t)e0.y << 32) | e0.x;
+			if (k0 == S16_EMPTY_KEY) {
+				return;
+			}
+			if (k0 == key) {
+				start = e0.z;
+				count = e0.w;
+				return;
+			}
+		}
+		const uint64_t k1 = ((uint64_t)e1.y << 32) | e1.x;
+		if (k1 == S16_EMPTY_KEY) {
 			return;
 		}
-		if (ek == key) {
-			start = e.z;
-			count = e.w;
+		if (k1 == key) {
+			start = e1.z;
+			count = e1.w;
 			return;
 		}
-		slot = (slot + 1) & s.mask;
+		first = 0;
+		group = (group + 1) & gmask;
 	}
 }
 
@@ -224,7 +301,7 @@ struct WaveCtx {
 	uint32_t lane;
 	// LDS regions of this wave
 	StageDesc *desc;      // [K] descriptors of the current join order
-	uint32_t *q;          // (K-1) queues, slot-major: q[(pos-1)*W*QCAP + slot*QCAP + idx]
+	uint32_t *q;          // (K-1) queues, slot-major: q[qoff<W,pos>() + slot*qcap<pos>() + idx]
 	uint32_t *pend_start; // [K][64]
 	uint32_t *pend_pref;  // [K][64] inclusive prefix of run lengths
 	uint32_t *batch0;     // [64] probe rows of the pinned stage-0 batch
@@ -232,6 +309,8 @@ struct WaveCtx {
 	uint32_t qsize[K], pend_T[K], pend_cur[K], pend_base[K], cnt[K];
 	const uint32_t *sel;
 	uint64_t in_pos, in_end;
+	uint32_t flush_token; // depends on the returned values of the counter atomics (ordering only)
+	bool wide0; // stage 0 of the current join order yields <= 1 match per tuple: take 256 tuples per step
 	// output
 	DevOut out;
 	bool emit;
@@ -302,10 +381,10 @@ __device__ __forceinline__ void emit_tuples(WaveCtx<W, K> &c, const Stage &s, Tu
 		const uint32_t qs = c.qsize[POS + 1];
 		if (valid) {
 			const uint32_t idx = qs + lane_rank(m);
-			uint32_t *qq = c.q + POS * (W * QCAP);
+			uint32_t *qq = c.q + qoff<W, POS + 1>();
 #pragma unroll
 			for (int i = 0; i < W; i++) {
-				qq[i * QCAP + idx] = t.s[i];
+				qq[i * qcap<POS + 1>() + idx] = t.s[i];
 			}
 		}
 		c.qsize[POS + 1] = qs + n;
@@ -356,10 +435,10 @@ __device__ __forceinline__ void resume_expansion(WaveCtx<W, K> &c) {
 	if (POS == 0) {
 		t.s[0] = c.batch0[src];
 	} else {
-		const uint32_t *qq = c.q + (POS - 1) * (W * QCAP);
+		const uint32_t *qq = c.q + qoff<W, POS>();
 #pragma unroll
 		for (int i = 0; i < W; i++) {
-			t.s[i] = qq[i * QCAP + c.pend_base[POS] + src];
+			t.s[i] = qq[i * qcap<POS>() + c.pend_base[POS] + src];
 		}
 	}
 	uint32_t id = 0;
@@ -401,10 +480,10 @@ __device__ __forceinline__ void run_stage(WaveCtx<W, K> &c) {
 		base = qs - n;
 		active = c.lane < n;
 		if (active) {
-			const uint32_t *qq = c.q + (POS - 1) * (W * QCAP);
+			const uint32_t *qq = c.q + qoff<W, POS>();
 #pragma unroll
 			for (int i = 0; i < W; i++) {
-				t.s[i] = qq[i * QCAP + base + c.lane];
+				t.s[i] = qq[i * qcap<POS>() + base + c.lane];
 			}
 		}
 		// popped; if the batch has to be expanded its cells stay in place: nothing pushes into this
@@ -445,6 +524,98 @@ __device__ __forceinline__ void run_stage(WaveCtx<W, K> &c) {
 			c.pend_cur[POS] = 0;
 			resume_expansion<W, K, POS>(c);
 		}
+	}
+}
+
+// Wide stage-0 step: 4 tuples per lane (256 per wave) with all loads of one kind issued back to back --
+// 4 probe rows, 4 keys, 4 bucket probes in flight per lane -- so a wave pays the sel -> key -> bucket
+// latency chain once per 256 tuples instead of once per 64.  Only for a stage-0 join that yields at most
+// one match per tuple (perfect table, unique-key table): matches go straight to queue 1 (capacity 320).
+template <int W, int K>
+__device__ __forceinline__ void run_stage0_wide(WaveCtx<W, K> &c) {
+	const Stage s = load_stage(&c.desc[0]);
+	const uint64_t left = c.in_end - c.in_pos;
+	const uint32_t n = left < 64 * WIDE ? (uint32_t)left : 64u * WIDE;
+	uint32_t row[WIDE];
+	bool act[WIDE];
+#pragma unroll
+	for (int i = 0; i < WIDE; i++) {
+		const uint32_t off = c.lane + 64u * i;
+		act[i] = off < n;
+		const uint64_t tp = c.in_pos + off;
+		row[i] = act[i] ? (c.sel ? c.sel[tp] : (uint32_t)tp) : 0u;
+	}
+	c.in_pos += n;
+	uint64_t key[WIDE];
+	bool valid[WIDE];
+#pragma unroll
+	for (int i = 0; i < WIDE; i++) {
+		Tuple<W> t;
+#pragma unroll
+		for (int q = 0; q < W; q++) {
+			t.s[q] = 0;
+		}
+		t.s[0] = row[i];
+		valid[i] = fetch_key<W>(s, t, act[i], key[i]);
+	}
+	uint32_t id[WIDE];
+	bool hit[WIDE];
+	if (s.kind == KIND_PERFECT) {
+#pragma unroll
+		for (int i = 0; i < WIDE; i++) {
+			hit[i] = lookup_perfect(s, key[i], valid[i], id[i]);
+		}
+	} else if (s.kind == KIND_S8) {
+		const uint4 *tab = (const uint4 *)s.table;
+		S8Probe p[WIDE];
+		bool any = false;
+#pragma unroll
+		for (int i = 0; i < WIDE; i++) {
+			s8_begin(s, key[i], valid[i], p[i]);
+			any = any || p[i].searching;
+		}
+		while (any) {
+			uint4 a[WIDE], b[WIDE];
+#pragma unroll
+			for (int i = 0; i < WIDE; i++) {
+				if (p[i].searching) {
+					a[i] = tab[p[i].group * 2];
+					b[i] = tab[p[i].group * 2 + 1];
+				}
+			}
+			any = false;
+#pragma unroll
+			for (int i = 0; i < WIDE; i++) {
+				if (p[i].searching) {
+					s8_check(s, p[i], a[i], b[i]);
+				}
+				any = any || p[i].searching;
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < WIDE; i++) {
+			hit[i] = p[i].hit;
+			id[i] = p[i].id;
+		}
+	} else {
+		// unique-key {key,start,count} table: count is 0 or 1
+#pragma unroll
+		for (int i = 0; i < WIDE; i++) {
+			uint32_t start, count;
+			lookup_s16(s, key[i], valid[i], start, count);
+			hit[i] = count != 0;
+			id[i] = (hit[i] && s.out_slot >= 0) ? s.rowids[start] : 0u;
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < WIDE; i++) {
+		Tuple<W> t;
+#pragma unroll
+		for (int q = 0; q < W; q++) {
+			t.s[q] = 0;
+		}
+		t.s[0] = row[i];
+		emit_tuples<W, K, 0>(c, s, t, id[i], hit[i]);
 	}
 }
 
@@ -496,20 +667,28 @@ __device__ __forceinline__ void run_until_idle(WaveCtx<W, K> &c, bool flushing) 
 		if (pick < 0) {
 			return;
 		}
-		dispatch<W, K, 0>(c, pick, resume);
+		if (pick == 0 && !resume && c.wide0) {
+			run_stage0_wide<W, K>(c);
+		} else {
+			dispatch<W, K, 0>(c, pick, resume);
+		}
 	}
 }
 
 template <int W, int K>
 __device__ __forceinline__ void flush_counts(WaveCtx<W, K> &c, unsigned long long *counts, int64_t round) {
 	if (c.lane == 0) {
+		unsigned long long seen = 0;
 #pragma unroll
 		for (int p = 0; p < K; p++) {
 			if (p < (int)c.k && c.cnt[p]) {
-				atomicAdd(&counts[((uint64_t)round * POLR_NSHARD + (blockIdx.x % POLR_NSHARD)) * c.k + p],
-				          (unsigned long long)c.cnt[p]);
+				// returning form: the wave cannot run past the point where `seen` is consumed before the
+				// add has been performed at device scope -- that is what orders it before the arrival ticket
+				seen |= atomicAdd(&counts[((uint64_t)round * POLR_NSHARD + (blockIdx.x % POLR_NSHARD)) * c.k + p],
+				                  (unsigned long long)c.cnt[p]);
 			}
 		}
+		c.flush_token = (uint32_t)(seen >> 63);
 	}
 #pragma unroll
 	for (int p = 0; p < K; p++) {
@@ -522,24 +701,48 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
                                                         const DevRound *__restrict__ rounds,
                                                         const uint64_t *__restrict__ unit_prefix, uint32_t n_rounds,
                                                         const uint32_t *__restrict__ unit_sizes, DevOut out,
-                                                        unsigned long long *__restrict__ counts) {
+                                                        unsigned long long *__restrict__ counts, SelfRoute sr) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const uint32_t wave_in_block = threadIdx.x >> 6;
+	STAMP(0)
+	if (sr.mpx) {
+		// self-routing launch: this launch reads descriptor slot (iter & 1), its last workgroup writes the
+		// other slot for the next launch (a late-starting idle workgroup must never see the new round)
+		const uint32_t slot = sr.iter & 1u;
+		rounds += slot;
+		unit_prefix += 2 * slot;
+		unit_sizes += slot;
+	}
 	const uint64_t total_units = unit_prefix[n_rounds];
+	if (sr.mpx && total_units == 0) {
+		// nothing routed (the run is over): keep the other slot empty too, or the launch after this one
+		// would find the stale round of two launches ago in it
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			const uint32_t next = (sr.iter + 1u) & 1u;
+			sr.prefix_base[2 * next] = 0;
+			sr.prefix_base[2 * next + 1] = 0;
+		}
+		return;
+	}
 	const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
 	const uint64_t wave_id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-	if (wave_id >= total_units) {
+	const uint64_t busy_waves = total_units < n_waves ? total_units : n_waves;
+	const uint32_t busy_blocks = (uint32_t)((busy_waves + (blockDim.x >> 6) - 1) / (blockDim.x >> 6));
+	if (blockIdx.x >= busy_blocks) {
+		return; // whole workgroup idle: not part of the arrival count either
+	}
+	if (!sr.mpx && wave_id >= total_units) {
 		return;
 	}
 	const uint32_t k = uni(pipe->k);
-	const uint32_t per_wave = K * STAGE_DESC_DWORDS + (K - 1) * W * QCAP + K * 64 * 2 + 64;
+	const uint32_t per_wave = K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64;
 	WaveCtx<W, K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
 	uint32_t *base = lds + wave_in_block * per_wave;
 	c.desc = (StageDesc *)base;
 	c.q = base + K * STAGE_DESC_DWORDS;
-	c.pend_start = c.q + (K - 1) * W * QCAP;
+	c.pend_start = c.q + qtotal<W, K>();
 	c.pend_pref = c.pend_start + K * 64;
 	c.batch0 = c.pend_pref + K * 64;
 #pragma unroll
@@ -548,6 +751,8 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 	}
 	c.sel = uniptr(pipe->sel);
 	c.in_pos = c.in_end = 0;
+	c.wide0 = false;
+	c.flush_token = 0;
 	c.out = out;
 	c.emit = false;
 	c.cur_chunk = NO_CHUNK;
@@ -556,8 +761,9 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 
 	const StageDesc *stages = uniptr(pipe->stages);
 	int64_t cur_round = -1;
+	STAMP(1)
 
-	for (uint64_t unit = wave_id; unit < total_units; unit += n_waves) {
+	for (uint64_t unit = wave_id; unit < total_units; unit += n_waves) { // (idle waves fall through)
 		uint32_t lo = 0, hi = n_rounds - 1; // last r with unit_prefix[r] <= unit
 		while (lo < hi) {
 			const uint32_t mid = (lo + hi + 1) >> 1;
@@ -582,6 +788,7 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 				dst[i] = src[i];
 			}
 			c.emit = uni(rounds[r].emit) != 0 && !c.overflow;
+			c.wide0 = uni(src[offsetof(StageDesc, unique) / 4]) != 0;
 		}
 		const uint64_t rb = uni64(rounds[r].begin);
 		const uint64_t rc = uni64(rounds[r].count);
@@ -594,12 +801,46 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 		}
 		run_until_idle(c, false);
 	}
+	STAMP(2)
 	if (cur_round >= 0) {
 		run_until_idle(c, true);
+		STAMP(3)
 		flush_counts(c, counts, cur_round);
 	}
 	if (c.cur_chunk != NO_CHUNK && c.lane == 0) {
 		out.chunk_count[c.cur_chunk] = c.fill;
+	}
+	STAMP(4)
+	if (sr.mpx) {
+		// Arrival: every busy workgroup publishes its counters (device-scope atomics above), then takes a
+		// ticket; the workgroup that takes the last one has seen all arrivals and routes the next round.
+		__shared__ uint32_t is_last;
+		__shared__ uint32_t tokens;
+		if (threadIdx.x == 0) {
+			tokens = 0;
+		}
+		__syncthreads();
+		if (c.lane == 0) {
+			atomicOr(&tokens, c.flush_token); // consumes the returned counter values of every wave
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			// all counter adds of this workgroup have been performed (their results were consumed above):
+			// take the arrival ticket; data crosses workgroups only through device-scope atomics
+			const uint32_t ticket = atomicAdd(sr.ticket, 1u + (tokens & 0u));
+			is_last = ticket == busy_blocks - 1 ? 1u : 0u;
+			if (is_last) {
+				atomicExch(sr.ticket, 0u);
+			}
+		}
+		__syncthreads();
+		STAMP(5)
+		if (is_last && wave_in_block == 0) {
+			const uint32_t next = (sr.iter + 1u) & 1u;
+			polr_router_step(sr.mpx, sr.rounds_base + next, sr.prefix_base + 2 * next, sr.unit_base + next, counts,
+			                 c.k, sr.resident_waves, c.lane, true, lds);
+		}
+		STAMP(6)
 	}
 }
 
@@ -608,9 +849,10 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 #define PASTE(a, b) PASTE2(a, b)
 
 static size_t lds_bytes_k(uint32_t W, uint32_t waves_per_block) {
-	return (size_t)waves_per_block *
-	       ((size_t)POLR_K * STAGE_DESC_DWORDS + (size_t)(POLR_K - 1) * W * QCAP + (size_t)POLR_K * 64 * 2 + 64) *
-	       sizeof(uint32_t);
+	const size_t queues = POLR_K <= 1 ? 0 : (size_t)W * QCAP1 + (size_t)(POLR_K - 2) * W * QCAPN;
+	return (size_t)waves_per_block * ((size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64) *
+	           sizeof(uint32_t) +
+	       64; // + the static arrival flag of a self-routing launch
 }
 
 extern "C++" size_t PASTE(polr_path_lds_bytes_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
@@ -620,7 +862,7 @@ extern "C++" size_t PASTE(polr_path_lds_bytes_k, POLR_K)(uint32_t W, uint32_t wa
 template <int W>
 static hipError_t launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const DevPipeline *pipe,
                            const DevRound *rounds, const uint64_t *unit_prefix, uint32_t n_rounds,
-                           const uint32_t *unit_sizes, DevOut out, unsigned long long *counts) {
+                           const uint32_t *unit_sizes, DevOut out, unsigned long long *counts, SelfRoute sr) {
 	// raise the dynamic-LDS limit once per (W, size): a host call we do not want on every launch
 	static size_t lds_set = 0;
 	if (lds > lds_set) {
@@ -632,7 +874,7 @@ static hipError_t launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t stream
 		lds_set = lds;
 	}
 	hipLaunchKernelGGL((polr_path_kernel<W, POLR_K>), grid, block, lds, stream, pipe, rounds, unit_prefix, n_rounds,
-	                   unit_sizes, out, counts);
+	                   unit_sizes, out, counts, sr);
 	return hipGetLastError();
 }
 
@@ -673,7 +915,7 @@ extern "C++" hipError_t PASTE(polr_launch_path_kernel_k, POLR_K)(uint32_t W, uin
                                                                  const DevPipeline *pipe, const DevRound *rounds,
                                                                  const uint64_t *unit_prefix, uint32_t n_rounds,
                                                                  const uint32_t *unit_sizes, DevOut out,
-                                                                 unsigned long long *counts) {
+                                                                 unsigned long long *counts, SelfRoute sr) {
 	const size_t lds = lds_bytes_k(W, waves_per_block);
 	dim3 grid(n_blocks), block(64 * waves_per_block);
 	if (W < 1 || W > POLR_K + 1) {
@@ -682,7 +924,7 @@ extern "C++" hipError_t PASTE(polr_launch_path_kernel_k, POLR_K)(uint32_t W, uin
 #define LAUNCH_CASE(N)                                                                                                 \
 	if (W == N) {                                                                                                      \
 		return launch_w<Wc<N>::v>(grid, block, lds, stream, pipe, rounds, unit_prefix, n_rounds, unit_sizes, out,      \
-		                          counts);                                                                             \
+		                          counts, sr);                                                                         \
 	}
 	POLR_FOR_EACH_W(LAUNCH_CASE)
 #undef LAUNCH_CASE
