@@ -37,7 +37,10 @@ struct polr_mpx {
 	uint64_t *chunk_offsets_dev = nullptr;
 	uint32_t *log_path = nullptr;
 	uint64_t *log_tuples = nullptr, *log_inter = nullptr;
-	uint32_t *done_host = nullptr; // pinned
+	uint32_t *done_host = nullptr;        // pinned, mapped: [0] routing steps completed, [1] done
+	volatile uint32_t *progress_dev = nullptr; // the device's view of done_host
+	uint32_t steps_base = 0;
+	bool pending_sync = false;
 	uint32_t unit_size = 256;
 	int poll_batch = 8;
 	uint32_t wide0_mask = 0;
@@ -63,9 +66,13 @@ static void drain_events(polr_mpx *m) {
 
 __global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_paths, uint64_t n_tuples,
                                      uint64_t n_chunks, uint32_t *log_path, uint64_t *log_tuples,
-                                     uint64_t *log_inter, uint32_t wide0_mask) {
+                                     uint64_t *log_inter, uint32_t wide0_mask, volatile uint32_t *progress,
+                                     uint32_t steps_done_init) {
 	m->wide0_mask = wide0_mask;
 	m->pad2 = 0;
+	m->progress = progress;
+	m->steps_done = steps_done_init; // monotonic across resets: the host throttles on differences
+	m->pad3 = 0;
 	m->core.Init(cfg.routing, n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
 	m->chunk_idx = m->chunk_end = 0;
 	m->n_tuples = n_tuples;
@@ -183,7 +190,11 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_inter, max_log * 8) : e;
-	e = e == hipSuccess ? hipHostMalloc((void **)&m->done_host, 64) : e;
+	e = e == hipSuccess ? hipHostMalloc((void **)&m->done_host, 64, hipHostMallocMapped) : e;
+	if (e == hipSuccess) {
+		memset(m->done_host, 0, 64);
+		e = hipHostGetDevicePointer((void **)&m->progress_dev, m->done_host, 0);
+	}
 	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8) : e;
 	if (e != hipSuccess) {
 		polr_mpx_destroy(m);
@@ -197,7 +208,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 		}
 	}
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, ctx->stream, m->dev, m->cfg, p->n_paths, p->n_tuples,
-	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask);
+	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask, m->progress_dev, 0u);
 	e = hipStreamSynchronize(ctx->stream);
 	if (e != hipSuccess) {
 		polr_mpx_destroy(m);
@@ -277,6 +288,12 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	const DevPipeline *dpd = materialize ? p->dev_mat : p->dev_count;
 	hipLaunchKernelGGL(polr_mpx_set_range_kernel, dim3(1), dim3(1), 0, st, m->dev, chunk_begin, chunk_end,
 	                   (const uint64_t *)m->chunk_offsets_dev, m->n_chunks, p->n_tuples);
+	if (m->pending_sync) { // a previous run left launches queued: settle before reading progress
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		m->pending_sync = false;
+	}
+	m->steps_base = ((volatile uint32_t *)m->done_host)[0];
+	((volatile uint32_t *)m->done_host)[1] = 0;
 	// prime: route the first round of this run into the descriptor slot the next launch reads
 	const uint32_t slot0 = m->iter & 1u;
 	hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(64), 0, st, m->dev, m->round_dev + slot0,
@@ -289,42 +306,48 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 	sr.ticket = m->ticket_dev;
 	sr.resident_waves = resident_waves;
 	sr.stamps = m->stamps_dev;
-	// every launch probes the round in its slot and its last workgroup routes the next one; the host only
-	// polls `done` once per batch of launches (launches after the end find an empty round and exit)
-	const int batch = m->poll_batch;
+	// Every launch probes the round in its slot and its last workgroup routes the next one.  The host
+	// never synchronises inside a run: it keeps a few launches queued ahead of the device's published
+	// progress (pinned host words written by the router) and stops when the router reports the end.
+	// Launches that were queued past the end find an empty round and exit.
+	volatile uint32_t *prog = (volatile uint32_t *)m->done_host;
+	const uint32_t look_ahead = 4;
+	uint32_t launched = 0;
+	const uint32_t base_steps = m->steps_base; // routing steps published before this run's prime step
 	for (;;) {
-		for (int i = 0; i < batch; i++) {
-			size_t ev = 0;
-			if (m->timing) {
-				ev = m->ev_used++;
-				if (ev >= m->ev_start.size()) {
-					hipEvent_t a, b;
-					HIPCHK(ctx, hipEventCreate(&a));
-					HIPCHK(ctx, hipEventCreate(&b));
-					m->ev_start.push_back(a);
-					m->ev_stop.push_back(b);
-				}
-				HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
-			}
-			sr.iter = m->iter++;
-			hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
-			                                       m->unit_size_dev, dout, m->counts_dev, sr);
-			if (e != hipSuccess) {
-				POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
-			}
-			if (m->timing) {
-				HIPCHK(ctx, hipEventRecord(m->ev_stop[ev], st));
-			}
+		const uint32_t steps = prog[0] - base_steps; // 1 after the prime step, +1 per routed launch
+		if (prog[1] && steps >= 1) {
+			break; // the router has seen the end of the range
 		}
-		HIPCHK(ctx, hipMemcpyAsync(m->done_host, &m->dev->done, 4, hipMemcpyDeviceToHost, st));
-		HIPCHK(ctx, hipStreamSynchronize(st));
+		if (launched + 1 > steps + look_ahead) {
+			continue; // spin: enough launches in flight
+		}
+		size_t ev = 0;
 		if (m->timing) {
-			drain_events(m);
+			ev = m->ev_used++;
+			if (ev >= m->ev_start.size()) {
+				hipEvent_t a, b;
+				HIPCHK(ctx, hipEventCreate(&a));
+				HIPCHK(ctx, hipEventCreate(&b));
+				m->ev_start.push_back(a);
+				m->ev_stop.push_back(b);
+			}
+			HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
 		}
-		if (*m->done_host) {
-			break;
+		sr.iter = m->iter++;
+		hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
+		                                       m->unit_size_dev, dout, m->counts_dev, sr);
+		if (e != hipSuccess) {
+			POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
 		}
+		if (m->timing) {
+			HIPCHK(ctx, hipEventRecord(m->ev_stop[ev], st));
+		}
+		launched++;
 	}
+	// (the queued tail is drained by whoever synchronises next: polr_mpx_finish, or the caller)
+	m->steps_base = prog[0];
+	m->pending_sync = true;
 	return POLR_OK;
 }
 
@@ -335,9 +358,14 @@ int polr_mpx_reset(polr_mpx *m, void *stream) {
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
+	if (m->pending_sync) { // launches of the previous pass may still be queued on its stream
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		m->pending_sync = false;
+	}
 	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8, st));
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
-	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask);
+	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask,
+	                   m->progress_dev, ((volatile uint32_t *)m->done_host)[0]);
 	return POLR_OK;
 }
 
@@ -383,6 +411,10 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	e = e == hipSuccess ? hipStreamSynchronize(st) : e;
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer finish failed: %s", hipGetErrorString(e));
+	}
+	m->pending_sync = false;
+	if (m->timing) {
+		drain_events(m);
 	}
 	return POLR_OK;
 }

@@ -29,6 +29,9 @@ struct DevMpx {
 	uint64_t last_path; // path of the round whose counters are still to be absorbed
 	uint32_t wide0_mask; // bit p: stage 0 of join order p takes the wide (256 tuples per step) path
 	uint32_t pad2;
+	// host-visible progress words (pinned, mapped host memory): [0] = routing steps completed, [1] = done
+	volatile uint32_t *progress;
+	uint32_t steps_done, pad3;
 	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
 };
 
@@ -61,6 +64,16 @@ struct SelfRoute {
 	uint32_t resident_waves;
 	unsigned long long *stamps; // diagnostic builds only (POLR_DIAG_STAMPS), else nullptr
 };
+
+// tell the host how far the device-side routing has got (it throttles its launch look-ahead on this)
+__device__ __forceinline__ void polr_publish_progress(DevMpx *m) {
+	m->steps_done++;
+	if (m->progress) {
+		m->progress[1] = m->done;
+		m->progress[0] = m->steps_done;
+		__threadfence_system();
+	}
+}
 
 // one routing decision
 __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, DevRound *round,
@@ -140,6 +153,7 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 	unit_size_out[0] = 64;
 	if (m->chunk_idx >= m->chunk_end) {
 		m->done = 1;
+		polr_publish_progress(m);
 		return;
 	}
 	uint64_t begin, tuples, path;
@@ -199,5 +213,6 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 	us = us < gran ? gran : (us > 2048 ? 2048 : us);
 	unit_size_out[0] = (uint32_t)us;
 	unit_prefix[1] = (tuples + us - 1) / us;
+	polr_publish_progress(m);
 }
 
