@@ -31,6 +31,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "duckdb-polr_amd", "python"))
+sys.path.insert(0, ROOT)
 from polr_amd import workloads  # noqa: E402
 
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
@@ -220,8 +221,57 @@ def make_scenario(name, enumerators=("each_last_once", "each_first_once")):
     return gold
 
 
+def make_job_light(scale=0.1):
+    """the bench.py workload (BASELINE.json configs[1]) at reduced scale: filtered scan -> thinned source
+    chunks, pinned left-deep pipeline, COUNT(*) sink -- through the reference's own SQL"""
+    from oracle import ref_run
+    wl = workloads.job_light_01(scale=scale)
+    ref = wl["ref"]
+    gold = {"scenario": "job_light_01", "scale": scale, "query": ref["query"], "routing": {}}
+
+    def run(settings):
+        workdir = tempfile.mkdtemp(prefix="polr_golden_")
+        try:
+            lines = []
+            for name, cols in ref["tables"].items():
+                lines += ref_run.table_lines(workdir, name, cols)
+            lines += ["sql SET threads TO 1"] + ["sql " + s for s in ref["settings"]] + ["sql " + s for s in settings]
+            lines.append("query q " + ref["query"])
+            script = os.path.join(workdir, "s.txt")
+            open(script, "w").write("\n".join(lines) + "\n")
+            proc = subprocess.run([DRIVER, script, os.path.join(workdir, "out")], capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError(proc.stdout + proc.stderr)
+            logs = [f for f in glob.glob(os.path.join(workdir, "out", "tmp", "*.csv"))
+                    if "-" not in os.path.basename(f)]
+            intms = glob.glob(os.path.join(workdir, "out", "tmp", "*-intms.txt"))
+            counts = [int(l.split(":")[1]) for l in proc.stdout.splitlines()
+                      if ":" in l and l.split(":")[0].strip().isdigit()]
+            answer = int(open(os.path.join(workdir, "out", "q.csv")).read().strip().splitlines()[1])
+            return open(logs[0]).read(), int(open(intms[0]).read().strip()), counts, answer
+        finally:
+            shutil.rmtree(workdir, ignore_errors=True)
+
+    base = ["PRAGMA enable_polr", "PRAGMA enable_log_tuples_routed", "PRAGMA disable_caching",
+            "SET join_enumerator TO 'each_last_once'"]
+    log, intms, counts, answer = run(base + ["SET multiplexer_routing TO 'alternate'"])
+    gold["alternate"] = {"matrix": parse_alt(log), "intms": intms}
+    gold["count_star"] = answer
+    for routing in ROUTINGS:
+        log, intms, counts, answer = run(base + ["SET multiplexer_routing TO '%s'" % routing])
+        assert answer == gold["count_star"]
+        gold["routing"][routing] = {"rounds": parse_rounds(log), "intms": intms, "tuple_counts": counts}
+    return gold
+
+
 def main():
-    names = sys.argv[1:] or list(SCENARIOS)
+    names = sys.argv[1:] or list(SCENARIOS) + ["job_light_01"]
+    if "job_light_01" in names:
+        names = [n for n in names if n != "job_light_01"]
+        gold = make_job_light()
+        path = os.path.join(HERE, "job_light_01.json")
+        json.dump(gold, open(path, "w"), separators=(",", ":"))
+        print("wrote", path, os.path.getsize(path), "bytes")
     for name in names:
         gold = make_scenario(name)
         path = os.path.join(HERE, name + ".json")

@@ -91,3 +91,28 @@ def test_device_alternate_matches_reference(gpu_ctx, name):
     assert st["num_intermediates"] == g["intms"]
     n_rows, _, overflow = out.stats()
     assert not overflow and n_rows == g["n_rows"]  # only path 0 forwards its output
+
+
+@pytest.mark.parametrize("routing", ["init_once", "opportunistic", "adaptive_reinit", "dynamic",
+                                     "exponential_backoff", "default_path"])
+def test_bench_workload_matches_reference(gpu_ctx, routing):
+    """bench.py's pipeline (selection list + thinned chunk offsets + COUNT(*) sink) at scale 0.1 against the
+    reference's own run of the same SQL"""
+    from test_oracle_golden import _job_light, job_light_budget
+    gold = common.load_golden("job_light_01")
+    wl, sel, n_rows, offs = _job_light()
+    joins = capi.build_joins(gpu_ctx, wl)
+    pipe = capi.Pipeline(gpu_ctx, list(wl["probe"]["cols"].values()), n_rows, joins, [[0, 1], [1, 0]])
+    pipe.set_selection(sel)
+    mpx = capi.DeviceMultiplexer(pipe, routing, regret_budget=job_light_budget(routing, n_rows))
+    mpx.set_chunk_offsets(offs)
+    mpx.run(0, len(offs) - 1)
+    st = mpx.finish()
+    path, tuples, inter = mpx.fetch_log()
+    g = gold["routing"][routing]
+    assert list(inter) == g["rounds"]
+    assert st["num_intermediates"] == g["intms"]
+    assert st["input_tuple_count_per_path"] == g["tuple_counts"]
+    # COUNT(*): the last join's output over all paths
+    k = 2
+    assert sum(st["stage_out"][p][k - 1] for p in range(2)) == gold["count_star"]

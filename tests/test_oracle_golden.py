@@ -160,3 +160,40 @@ def test_row_layout_and_capacity():
     assert big.capacity == 131072
     heads = big.bucket_heads()
     assert (heads != 2**64 - 1).sum() <= 40_000
+
+
+def _job_light():
+    import bench
+    wl = workloads.job_light_01(scale=0.1)
+    sel = wl["probe"]["filter_sel"]
+    n_rows = len(wl["probe"]["cols"]["movie_id"])
+    offs = bench.chunk_offsets_for(sel, n_rows, 1024)
+    return wl, sel, n_rows, offs
+
+
+def job_light_budget(routing, n_rows):
+    # EXPONENTIAL_BACKOFF re-purposes regret_budget as source est_card/10240/10/threads
+    # (polar_config.cpp:115-120); the source's estimated_cardinality is the table's row count
+    return n_rows / 10240.0 / 10 / 1 if routing == "exponential_backoff" else 0.01
+
+
+@pytest.mark.parametrize("routing", ["alternate", "init_once", "opportunistic", "adaptive_reinit", "dynamic",
+                                     "exponential_backoff", "default_path"])
+def test_job_light_bench_pipeline(routing):
+    """the bench.py workload at scale 0.1 through the reference's own SQL (filtered scan -> thinned source
+    chunks, pinned left-deep pipeline, both joins probed with mc.movie_id, COUNT(*))"""
+    gold = common.load_golden("job_light_01")
+    wl, sel, n_rows, offs = _job_light()
+    joins = [orc.JoinSpec(orc.HashTable(j["keys"], []), j["key_src"]) for j in wl["joins"]]
+    res = orc.run_pipeline(list(wl["probe"]["cols"].values()), joins, [[0, 1], [1, 0]], routing=routing,
+                           caching=False, sel=sel, chunk_offsets=offs, collect_output=False,
+                           regret_budget=job_light_budget(routing, n_rows))
+    assert res["num_output_rows"] == gold["count_star"]
+    if routing == "alternate":
+        assert np.array_equal(res["alt_matrix"], np.asarray(gold["alternate"]["matrix"], dtype=np.uint64))
+        assert res["num_intermediates"] == gold["alternate"]["intms"]
+    else:
+        g = gold["routing"][routing]
+        assert list(res["intermediates_per_round"]) == g["rounds"]
+        assert res["num_intermediates"] == g["intms"]
+        assert res["input_tuple_count_per_path"] == g["tuple_counts"]
