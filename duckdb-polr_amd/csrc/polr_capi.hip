@@ -1425,24 +1425,39 @@ void polr_out_destroy(polr_out *o) {
 // resident at once (occupancy of the instantiation x CUs), waves grid-stride over units of 64..1024
 // tuples sized so that a small routing round still spreads over the chip while a table-sized round
 // gives every resident wave a few units.
+uint32_t polr_waves_per_block(polr_pipeline *p, bool materialize) {
+	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
+	uint32_t &cached = materialize ? p->wpb_mat : p->wpb_count;
+	if (cached == 0) {
+		for (uint32_t w : {4u, 2u, 1u}) {
+			// leave room for at least two workgroups per CU when possible
+			if (polr_path_lds_bytes(dp.k, dp.W, w) <= (w == 1 ? 160u * 1024 : 80u * 1024)) {
+				cached = w;
+				break;
+			}
+		}
+	}
+	return cached;
+}
+
 uint32_t polr_resident_waves(polr_pipeline *p, bool materialize) {
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
+	const uint32_t wpb = polr_waves_per_block(p, materialize);
 	int &cached = materialize ? p->blocks_per_cu_mat : p->blocks_per_cu_count;
 	if (cached == 0) {
-		cached = polr_path_occupancy(dp.k, dp.W, 4);
+		cached = polr_path_occupancy(dp.k, dp.W, wpb);
 		if (cached > 8) {
 			cached = 8;
 		}
 	}
-	return (uint32_t)p->ctx->n_cus * (uint32_t)cached * 4u;
+	return (uint32_t)p->ctx->n_cus * (uint32_t)cached * wpb;
 }
 
 int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, uint32_t *unit_size,
                      uint32_t *n_blocks_max) {
-	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
-	const size_t lds = polr_path_lds_bytes(dp.k, dp.W, 4);
-	if (lds > 160 * 1024) {
-		p->ctx->err = "per-workgroup LDS queues exceed 160 KB (too many joins x carried ids)";
+	const uint32_t wpb = polr_waves_per_block(p, materialize);
+	if (wpb == 0) {
+		p->ctx->err = "per-wave LDS queues exceed 160 KB (too many joins x carried ids)";
 		return POLR_E_UNSUPPORTED;
 	}
 	const uint64_t waves = polr_resident_waves(p, materialize);
@@ -1450,7 +1465,7 @@ int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, 
 	us = ((us + 63) / 64) * 64;
 	us = std::min<uint64_t>(std::max<uint64_t>(us, 64), 2048);
 	*unit_size = (uint32_t)us;
-	*n_blocks_max = (uint32_t)(waves / 4);
+	*n_blocks_max = (uint32_t)(waves / wpb);
 	return POLR_OK;
 }
 
@@ -1530,7 +1545,8 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 	HIPCHK(ctx, hipMemcpyAsync(p->unit_sizes_dev, usizes.data(), (uint64_t)n_rounds * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(ctx, hipStreamSynchronize(st)); // prefix is a local vector
 	const uint64_t total_units = prefix[n_rounds];
-	const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(max_blocks, (total_units + 3) / 4);
+	const uint32_t wpb = polr_waves_per_block(p, materialize);
+	const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(max_blocks, (total_units + wpb - 1) / wpb);
 	DevOut dout;
 	memset(&dout, 0, sizeof(dout));
 	if (out) {
@@ -1538,7 +1554,7 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 		out->stats_valid = false;
 	}
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
-	hipError_t e = polr_launch_path_kernel(dp.W, dp.k, n_blocks, 4, st, materialize ? p->dev_mat : p->dev_count,
+	hipError_t e = polr_launch_path_kernel(dp.W, dp.k, n_blocks, wpb, st, materialize ? p->dev_mat : p->dev_count,
 	                                       p->rounds_dev, p->prefix_dev, n_rounds, p->unit_sizes_dev, dout,
 	                                       p->shards_dev, SelfRoute {});
 	if (e != hipSuccess) {

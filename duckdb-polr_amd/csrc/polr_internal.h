@@ -67,6 +67,7 @@ struct polr_pipeline {
 	DevPipeline *dev_count = nullptr, *dev_mat = nullptr;
 	StageDesc *stages_count = nullptr, *stages_mat = nullptr; // [n_paths][POLR_KMAX] each
 	int blocks_per_cu_count = 0, blocks_per_cu_mat = 0;       // measured residency of the path kernel
+	uint32_t wpb_count = 0, wpb_mat = 0;                      // waves per workgroup (4, or fewer when the LDS queues are wide)
 	// launch scratch (grown on demand)
 	DevRound *rounds_dev = nullptr;
 	uint64_t *prefix_dev = nullptr;
@@ -142,3 +143,4 @@ void polr_launch_chunk_prefix(hipStream_t st, const uint32_t *chunk_count, uint3
 int polr_plan_launch(polr_pipeline *p, bool materialize, uint64_t total_tuples, uint32_t *unit_size,
                      uint32_t *n_blocks_max);
 uint32_t polr_resident_waves(polr_pipeline *p, bool materialize);
+uint32_t polr_waves_per_block(polr_pipeline *p, bool materialize); // 0: does not fit at all

@@ -335,7 +335,8 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 			HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
 		}
 		sr.iter = m->iter++;
-		hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, 4, st, dpd, m->round_dev, m->prefix_dev, 1,
+		hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, polr_waves_per_block(p, materialize), st, dpd,
+		                                       m->round_dev, m->prefix_dev, 1,
 		                                       m->unit_size_dev, dout, m->counts_dev, sr);
 		if (e != hipSuccess) {
 			POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));

@@ -224,7 +224,7 @@ OperatorResultType PhysicalHashJoin::Execute(ExecutionContext &context, DataChun
 	round.path = 0;
 	round.emit = 1;
 	uint64_t produced = 0;
-	uint64_t max_chunks = 64;
+	uint64_t max_chunks = 8192; // every emitting wave owns a partially filled chunk: waves + outputs/1024
 	for (;;) {
 		if (!state.out) {
 			Check(ctx, polr_out_create(state.pipe, 1024, max_chunks, &state.out), "polr_out_create");

@@ -169,6 +169,8 @@ void polr_pipeline_destroy(polr_pipeline *p);
  * row, slot 1+j = build row of join j in the ORIGINAL join order, i.e. PhysicalAdaptiveUnion
  * (src/execution/operator/polr/physical_adaptive_union.cpp:37-76) is already applied.
  * ------------------------------------------------------------------------------------------- */
+/* max_chunks must cover outputs/chunk_capacity plus one partially filled chunk per emitting wave (at most the
+ * resident waves of the device, <= 8192); too small -> POLR_E_OVERFLOW with exact counters, retry larger. */
 int polr_out_create(polr_pipeline *p, uint32_t chunk_capacity, uint64_t max_chunks, polr_out **out);
 int polr_out_reset(polr_out *o, void *stream);
 int polr_out_stats(polr_out *o, void *stream, uint64_t *n_rows, uint64_t *n_chunks, uint32_t *overflowed);

@@ -119,12 +119,12 @@ def test_bucket_collisions(gpu_ctx):
     """many distinct keys that land in the same slot neighbourhood: long linear-probe runs"""
     from polr_amd import capi as _c  # noqa: F401
     L = orc.lib()
-    cap = 2048
+    cap = 1024  # the device table of <= 512 keys has 1024 slots (load factor <= 0.5, floor 1024)
     cand = np.arange(1, 400_000, dtype=np.uint32)
     h = np.array([L.orc_murmurhash64(int(x)) & (cap - 1) for x in cand[:60_000]], dtype=np.int64)
-    colliding = cand[:60_000][(h >= 100) & (h < 104)][:700].astype(np.int32)
-    assert len(colliding) >= 200
-    bk = colliding[:600] if len(colliding) >= 600 else colliding
+    colliding = cand[:60_000][(h >= 100) & (h < 104)].astype(np.int32)
+    assert 150 <= len(colliding) <= 500  # all of them hash into 4 adjacent slots: probe runs of 150+
+    bk = colliding
     rng = np.random.default_rng(5)
     pk = np.concatenate([rng.choice(colliding, 3000), rng.integers(1, 400_000, 3000).astype(np.int32)])
     run_both(gpu_ctx, [pk], [([bk], [], [(-1, 0)], None, None)], [[0]])
@@ -143,7 +143,7 @@ def test_payload_widths(gpu_ctx, dtype):
     oht = orc.HashTable([bk], [pay], payload_valid=[pvalid])
     ght = capi.HashTable.from_columns(gpu_ctx, [bk], [pay], payload_valid=[pvalid]).finalize_hash()
     pipe = capi.Pipeline(gpu_ctx, [pk], len(pk), [(ght, [(-1, 0)])], [[0]])
-    out = capi.Output(pipe, 1024, 64)
+    out = capi.Output(pipe, 1024, 8192)  # every emitting wave owns a (partially filled) chunk
     pipe.probe_rounds([(0, len(pk), 0, 1)], out=out)
     ids = out.fetch_ids()
     data, valid = out.materialize(0, 0, pay.dtype)
