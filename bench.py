@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--regret-budget", type=float, default=0.01)
     ap.add_argument("--init-tuple-count", type=int, default=1024)
     ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
+    ap.add_argument("--max-join-orders", type=int, default=8, help="SET max_join_orders (bank size cap)")
     ap.add_argument("--executors", type=int, default=1,
                     help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
                          "contiguous share of the source chunks on its own HIP stream -- the counterpart of the "
@@ -164,6 +165,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
+    # executors run on separate HIP streams; let the runtime map them to separate hardware queues
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -189,7 +192,7 @@ def main():
     wl = wl0 if rank == 0 else build_workload(args.workload, args.scale,
                                               pdist.probe_partition_seed(workloads.SEED, rank))
     k = len(wl0["joins"])
-    paths = workloads.default_paths(k, "each_last_once")
+    paths = workloads.default_paths(k, "each_last_once")[:max(1, args.max_join_orders)]
 
     # build sides: rank 0 builds in HBM, everyone else receives them over RCCL (one broadcast per buffer)
     joins = []
@@ -245,32 +248,25 @@ def main():
     offs = chunk_offsets_for(sel, n_rows, V)
     n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
     E = max(1, min(args.executors, n_chunks))
-    import threading
     execs = []
     for e in range(E):
         m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
                                    init_tuple_count=args.init_tuple_count, log_rounds=False)
         if offs is not None:
             m.set_chunk_offsets(offs)
-        st_e = torch.cuda.Stream(device=dev)
-        execs.append((m, st_e, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
+        execs.append((m, None, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
     results = [None] * E
-
-    def run_executor(e):
-        m, st_e, c0, c1 = execs[e]
-        m.reset(st_e.cuda_stream)
-        m.run(c0, c1, stream=st_e.cuda_stream)
-        results[e] = m.finish(st_e.cuda_stream)
+    mpxs = [x[0] for x in execs]
+    ranges = [(x[2], x[3]) for x in execs]
 
     def step():
+        for m in mpxs:
+            m.reset()
         if E == 1:
-            run_executor(0)
+            mpxs[0].run(*ranges[0])
         else:
-            ts = [threading.Thread(target=run_executor, args=(e,)) for e in range(E)]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
+            capi.run_many(mpxs, ranges)  # one host thread pumps all executors; rounds overlap on the device
+        results[:] = capi.finish_many(mpxs)
         return results
 
     def merged(res):

@@ -22,7 +22,7 @@
 #define POLR_WMAX (1 + POLR_KMAX)
 // per-round counters are sharded by workgroup so a table-sized round does not serialise thousands of
 // atomics on k words; readers sum the shards
-#define POLR_NSHARD 32
+#define POLR_NSHARD 32 // (the router sums the shards with one half-wave per counter: keep it 32)
 
 enum { KIND_NONE = 0, KIND_PERFECT = 1, KIND_S8 = 2, KIND_S16 = 3 };
 

@@ -41,6 +41,8 @@ struct polr_mpx {
 	volatile uint32_t *progress_dev = nullptr; // the device's view of done_host
 	uint32_t steps_base = 0;
 	bool pending_sync = false;
+	hipStream_t own_stream = nullptr;  // used when the caller passes no stream
+	hipStream_t last_stream = nullptr; // where the queued tail of the last run sits
 	uint32_t unit_size = 256;
 	int poll_batch = 8;
 	uint32_t wide0_mask = 0;
@@ -185,6 +187,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	e = e == hipSuccess ? hipMalloc((void **)&m->prefix_dev, 4 * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->unit_size_dev, 2 * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->ticket_dev, 64) : e;
+	e = e == hipSuccess ? hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) : e;
 	e = e == hipSuccess ? hipMemset(m->ticket_dev, 0, 64) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
@@ -244,10 +247,21 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 	return POLR_OK;
 }
 
-int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out) {
-	if (!m) {
-		return POLR_E_INVALID;
-	}
+// ---- a run = begin (set range, prime the first round) + a non-blocking pump that keeps a few
+// self-routing launches queued ahead of the progress the device publishes -------------------------
+struct RunState {
+	polr_mpx *m = nullptr;
+	hipStream_t st = nullptr;
+	SelfRoute sr;
+	DevOut dout;
+	const DevPipeline *dpd = nullptr;
+	uint32_t W = 0, k = 0, max_blocks = 0, wpb = 0;
+	uint32_t launched = 0, base_steps = 0;
+	bool finished = false;
+};
+
+static int run_begin(RunState &rs, polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
+                     polr_out *out, uint32_t share) {
 	polr_pipeline *p = m->pipe;
 	polr_ctx *ctx = p->ctx;
 	if (chunk_begin > chunk_end || chunk_end > m->n_chunks) {
@@ -258,7 +272,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 		POLR_FAIL(ctx, POLR_E_INVALID, "output object belongs to another pipeline");
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = polr_stream(ctx, stream);
+	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
 	const bool materialize = out != nullptr;
 	uint32_t unit_unused, max_blocks;
 	int rc = polr_plan_launch(p, materialize, p->n_tuples, &unit_unused, &max_blocks);
@@ -271,85 +285,134 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 		HIPCHK(ctx, hipMemset(m->stamps_dev, 0, 4096 * 8 * 8));
 	}
 #endif
-	uint32_t resident_waves = polr_resident_waves(p, materialize);
-	if (const char *e = getenv("POLR_EXP_WAVES")) { // experiment knob: pretend fewer resident waves (bigger units)
-		resident_waves = (uint32_t)atoi(e);
-	}
-	if (const char *e = getenv("POLR_EXP_BLOCKS")) {
-		max_blocks = (uint32_t)atoi(e);
-	}
-	DevOut dout;
-	memset(&dout, 0, sizeof(dout));
+	// executors that run concurrently share the device: each sizes its units and grid for its share
+	uint32_t resident_waves = std::max<uint32_t>(polr_resident_waves(p, materialize) / std::max<uint32_t>(share, 1), 256);
+	const uint32_t wpb = polr_waves_per_block(p, materialize);
+	max_blocks = std::max<uint32_t>(max_blocks / std::max<uint32_t>(share, 1), 64);
+	rs.m = m;
+	rs.st = st;
+	memset(&rs.dout, 0, sizeof(rs.dout));
 	if (out) {
-		dout = out->dev;
+		rs.dout = out->dev;
 		out->stats_valid = false;
 	}
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
-	const DevPipeline *dpd = materialize ? p->dev_mat : p->dev_count;
-	hipLaunchKernelGGL(polr_mpx_set_range_kernel, dim3(1), dim3(1), 0, st, m->dev, chunk_begin, chunk_end,
-	                   (const uint64_t *)m->chunk_offsets_dev, m->n_chunks, p->n_tuples);
+	rs.dpd = materialize ? p->dev_mat : p->dev_count;
+	rs.W = dp.W;
+	rs.k = dp.k;
+	rs.max_blocks = max_blocks;
+	rs.wpb = wpb;
 	if (m->pending_sync) { // a previous run left launches queued: settle before reading progress
-		HIPCHK(ctx, hipStreamSynchronize(st));
+		HIPCHK(ctx, hipStreamSynchronize(m->last_stream ? m->last_stream : st));
 		m->pending_sync = false;
 	}
+	hipLaunchKernelGGL(polr_mpx_set_range_kernel, dim3(1), dim3(1), 0, st, m->dev, chunk_begin, chunk_end,
+	                   (const uint64_t *)m->chunk_offsets_dev, m->n_chunks, p->n_tuples);
 	m->steps_base = ((volatile uint32_t *)m->done_host)[0];
 	((volatile uint32_t *)m->done_host)[1] = 0;
 	// prime: route the first round of this run into the descriptor slot the next launch reads
 	const uint32_t slot0 = m->iter & 1u;
 	hipLaunchKernelGGL(polr_mpx_router_kernel, dim3(1), dim3(64), 0, st, m->dev, m->round_dev + slot0,
 	                   m->prefix_dev + 2 * slot0, m->unit_size_dev + slot0, m->counts_dev, p->k, resident_waves);
-	SelfRoute sr;
-	sr.mpx = m->dev;
-	sr.rounds_base = m->round_dev;
-	sr.prefix_base = m->prefix_dev;
-	sr.unit_base = m->unit_size_dev;
-	sr.ticket = m->ticket_dev;
-	sr.resident_waves = resident_waves;
-	sr.stamps = m->stamps_dev;
-	// Every launch probes the round in its slot and its last workgroup routes the next one.  The host
-	// never synchronises inside a run: it keeps a few launches queued ahead of the device's published
-	// progress (pinned host words written by the router) and stops when the router reports the end.
-	// Launches that were queued past the end find an empty round and exit.
-	volatile uint32_t *prog = (volatile uint32_t *)m->done_host;
-	const uint32_t look_ahead = 4;
-	uint32_t launched = 0;
-	const uint32_t base_steps = m->steps_base; // routing steps published before this run's prime step
-	for (;;) {
-		const uint32_t steps = prog[0] - base_steps; // 1 after the prime step, +1 per routed launch
-		if (prog[1] && steps >= 1) {
-			break; // the router has seen the end of the range
-		}
-		if (launched + 1 > steps + look_ahead) {
-			continue; // spin: enough launches in flight
-		}
-		size_t ev = 0;
-		if (m->timing) {
-			ev = m->ev_used++;
-			if (ev >= m->ev_start.size()) {
-				hipEvent_t a, b;
-				HIPCHK(ctx, hipEventCreate(&a));
-				HIPCHK(ctx, hipEventCreate(&b));
-				m->ev_start.push_back(a);
-				m->ev_stop.push_back(b);
-			}
-			HIPCHK(ctx, hipEventRecord(m->ev_start[ev], st));
-		}
-		sr.iter = m->iter++;
-		hipError_t e = polr_launch_path_kernel(dp.W, dp.k, max_blocks, polr_waves_per_block(p, materialize), st, dpd,
-		                                       m->round_dev, m->prefix_dev, 1,
-		                                       m->unit_size_dev, dout, m->counts_dev, sr);
-		if (e != hipSuccess) {
-			POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
-		}
-		if (m->timing) {
-			HIPCHK(ctx, hipEventRecord(m->ev_stop[ev], st));
-		}
-		launched++;
-	}
-	// (the queued tail is drained by whoever synchronises next: polr_mpx_finish, or the caller)
-	m->steps_base = prog[0];
-	m->pending_sync = true;
+	rs.sr.mpx = m->dev;
+	rs.sr.rounds_base = m->round_dev;
+	rs.sr.prefix_base = m->prefix_dev;
+	rs.sr.unit_base = m->unit_size_dev;
+	rs.sr.ticket = m->ticket_dev;
+	rs.sr.resident_waves = resident_waves;
+	rs.sr.stamps = m->stamps_dev;
+	rs.sr.iter = 0;
+	rs.launched = 0;
+	rs.base_steps = m->steps_base;
+	rs.finished = false;
+	m->last_stream = st;
 	return POLR_OK;
+}
+
+// Every launch probes the round in its slot and its last workgroup routes the next one.  The host never
+// synchronises inside a run: it keeps a few launches queued ahead of the progress the device publishes
+// (pinned host words written by the router) and stops when the router reports the end of the range.
+// Launches queued past the end find an empty round and exit.  Non-blocking: returns after at most one launch.
+static int run_pump(RunState &rs) {
+	polr_mpx *m = rs.m;
+	polr_ctx *ctx = m->pipe->ctx;
+	volatile uint32_t *prog = (volatile uint32_t *)m->done_host;
+	const uint32_t look_ahead = 3;
+	const uint32_t steps = prog[0] - rs.base_steps; // 1 after the prime step, +1 per routed launch
+	if (prog[1] && steps >= 1) {
+		rs.finished = true; // the router has seen the end of the range
+		m->steps_base = prog[0];
+		m->pending_sync = true; // the queued tail is drained by whoever synchronises next
+		return POLR_OK;
+	}
+	if (rs.launched + 1 > steps + look_ahead) {
+		return POLR_OK; // enough launches in flight
+	}
+	size_t ev = 0;
+	if (m->timing) {
+		ev = m->ev_used++;
+		if (ev >= m->ev_start.size()) {
+			hipEvent_t a, b;
+			HIPCHK(ctx, hipEventCreate(&a));
+			HIPCHK(ctx, hipEventCreate(&b));
+			m->ev_start.push_back(a);
+			m->ev_stop.push_back(b);
+		}
+		HIPCHK(ctx, hipEventRecord(m->ev_start[ev], rs.st));
+	}
+	rs.sr.iter = m->iter++;
+	hipError_t e = polr_launch_path_kernel(rs.W, rs.k, rs.max_blocks, rs.wpb, rs.st, rs.dpd, m->round_dev,
+	                                       m->prefix_dev, 1, m->unit_size_dev, rs.dout, m->counts_dev, rs.sr);
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "path kernel launch failed: %s", hipGetErrorString(e));
+	}
+	if (m->timing) {
+		HIPCHK(ctx, hipEventRecord(m->ev_stop[ev], rs.st));
+	}
+	rs.launched++;
+	return POLR_OK;
+}
+
+int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out) {
+	if (!m) {
+		return POLR_E_INVALID;
+	}
+	RunState rs;
+	int rc = run_begin(rs, m, stream, chunk_begin, chunk_end, out, 1);
+	while (!rc && !rs.finished) {
+		rc = run_pump(rs);
+	}
+	return rc;
+}
+
+// Several executors at once (the reference runs one PipelineExecutor + MultiplexerState per worker
+// thread over morsels of one pipeline, pipeline.cpp:145-174): every multiplexer routes its own chunk
+// range on its own stream; one host thread pumps them round-robin, so their routing rounds overlap on
+// the device instead of queueing behind each other.
+int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin, const uint64_t *chunk_end,
+                      uint32_t n, polr_out *out) {
+	if (!ms || !chunk_begin || !chunk_end || n == 0) {
+		return POLR_E_INVALID;
+	}
+	std::vector<RunState> rs(n);
+	int rc = POLR_OK;
+	for (uint32_t i = 0; i < n && !rc; i++) {
+		if (!ms[i] || ms[i]->pipe != ms[0]->pipe) {
+			return POLR_E_INVALID;
+		}
+		rc = run_begin(rs[i], ms[i], streams ? streams[i] : nullptr, chunk_begin[i], chunk_end[i], out, n);
+	}
+	bool all_done = false;
+	while (!rc && !all_done) {
+		all_done = true;
+		for (uint32_t i = 0; i < n && !rc; i++) {
+			if (!rs[i].finished) {
+				rc = run_pump(rs[i]);
+				all_done = all_done && rs[i].finished;
+			}
+		}
+	}
+	return rc;
 }
 
 int polr_mpx_reset(polr_mpx *m, void *stream) {
@@ -358,7 +421,7 @@ int polr_mpx_reset(polr_mpx *m, void *stream) {
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = polr_stream(ctx, stream);
+	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
 	if (m->pending_sync) { // launches of the previous pass may still be queued on its stream
 		HIPCHK(ctx, hipStreamSynchronize(st));
 		m->pending_sync = false;
@@ -402,7 +465,7 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = polr_stream(ctx, stream);
+	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
 	if (!m->stats_dev) {
 		HIPCHK(ctx, hipMalloc((void **)&m->stats_dev, sizeof(polr_mpx_stats)));
 	}
@@ -420,6 +483,35 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	return POLR_OK;
 }
 
+// finish several executors: all closing kernels and read-backs are queued first, then each stream is
+// synchronised once (saves n-1 serial round trips)
+int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
+	if (!ms || !stats || n == 0) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = ms[0]->pipe->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	for (uint32_t i = 0; i < n; i++) {
+		polr_mpx *m = ms[i];
+		hipStream_t st = m->last_stream ? m->last_stream : m->own_stream;
+		if (!m->stats_dev) {
+			HIPCHK(ctx, hipMalloc((void **)&m->stats_dev, sizeof(polr_mpx_stats)));
+		}
+		hipLaunchKernelGGL(polr_mpx_finish_kernel, dim3(1), dim3(64), 0, st, m->dev, m->counts_dev, m->pipe->k,
+		                   m->stats_dev);
+		HIPCHK(ctx, hipMemcpyAsync(&stats[i], m->stats_dev, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st));
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		polr_mpx *m = ms[i];
+		HIPCHK(ctx, hipStreamSynchronize(m->last_stream ? m->last_stream : m->own_stream));
+		m->pending_sync = false;
+		if (m->timing) {
+			drain_events(m);
+		}
+	}
+	return POLR_OK;
+}
+
 int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tuples, uint64_t *intermediates,
                        uint64_t max_rounds, uint64_t *n_rounds) {
 	if (!m || !n_rounds) {
@@ -427,7 +519,7 @@ int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tupl
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = polr_stream(ctx, stream);
+	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
 	DevMpx h;
 	HIPCHK(ctx, hipMemcpyAsync(&h, m->dev, sizeof(DevMpx), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipStreamSynchronize(st));
@@ -467,6 +559,10 @@ void polr_mpx_destroy(polr_mpx *m) {
 	}
 	if (m->ticket_dev) {
 		hipFree(m->ticket_dev);
+	}
+	if (m->own_stream) {
+		hipStreamSynchronize(m->own_stream);
+		hipStreamDestroy(m->own_stream);
 	}
 	if (m->stats_dev) {
 		hipFree(m->stats_dev);

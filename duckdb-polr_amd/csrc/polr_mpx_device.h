@@ -69,9 +69,11 @@ struct SelfRoute {
 __device__ __forceinline__ void polr_publish_progress(DevMpx *m) {
 	m->steps_done++;
 	if (m->progress) {
+		// plain stores to mapped host memory: they land in order of issue soon enough; a stale read on the
+		// host costs at most one extra (empty) launch, never correctness -- no system-scope fence on the
+		// critical path of every routing step
 		m->progress[1] = m->done;
 		m->progress[0] = m->steps_done;
-		__threadfence_system();
 	}
 }
 
@@ -118,22 +120,30 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 	// One wave: lane s sums shard s of the k counters, a shuffle tree adds the shards, lane 0 routes.
 	uint64_t s = 0;
 	{
-		for (uint32_t j = 0; j < k; j++) {
+		// two counters per pass: lanes 0..31 sum the shards of counter j, lanes 32..63 those of j+1
+		for (uint32_t j0 = 0; j0 < k; j0 += 2) {
+			const uint32_t j = j0 + (lane >> 5);
+			const uint32_t shard = lane & 31u;
 			unsigned long long v = 0;
-			if (lane < POLR_NSHARD) {
+			if (j < k) {
 				if (coherent) {
-					v = atomicExch(&counts[(uint64_t)lane * k + j], 0ull);
+					v = atomicExch(&counts[(uint64_t)shard * k + j], 0ull);
 				} else {
-					v = counts[(uint64_t)lane * k + j];
-					counts[(uint64_t)lane * k + j] = 0;
+					v = counts[(uint64_t)shard * k + j];
+					counts[(uint64_t)shard * k + j] = 0;
 				}
 			}
-			for (int d = 32; d > 0; d >>= 1) {
-				v += __shfl_down(v, d, 64);
+			for (int d = 16; d > 0; d >>= 1) {
+				v += __shfl_down(v, d, 32);
 			}
+			const unsigned long long v_hi = __shfl(v, 32, 64);
 			if (lane == 0) {
 				s += v;
-				mg->stage_out[m->last_path][j] += v;
+				mg->stage_out[m->last_path][j0] += v;
+				if (j0 + 1 < k) {
+					s += v_hi;
+					mg->stage_out[m->last_path][j0 + 1] += v_hi;
+				}
 			}
 		}
 		if (lane != 0) {

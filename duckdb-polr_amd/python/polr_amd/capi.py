@@ -29,7 +29,7 @@ EXPORTS = [
     "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
-    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time",
+    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many",
 ]
 
 
@@ -122,6 +122,8 @@ def load():
     L.polr_mpx_destroy.argtypes = [vp]
     L.polr_mpx_destroy.restype = None
     L.polr_mpx_reset.argtypes = [vp, vp]
+    L.polr_mpx_run_many.argtypes = [vp, vp, vp, vp, u32, vp]
+    L.polr_mpx_finish_many.argtypes = [vp, u32, vp]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
     _lib = L
@@ -442,6 +444,33 @@ class DeviceMultiplexer:
             self.close()
         except Exception:
             pass
+
+
+def run_many(mpxs, ranges, out=None):
+    """polr_mpx_run_many: mpxs[i] routes chunks ranges[i] = (begin, end) concurrently (own streams)"""
+    n = len(mpxs)
+    hs = (C.c_void_p * n)(*[m.h for m in mpxs])
+    b = np.ascontiguousarray([r[0] for r in ranges], dtype=np.uint64)
+    e = np.ascontiguousarray([r[1] for r in ranges], dtype=np.uint64)
+    ctx = mpxs[0].ctx
+    ctx.check(ctx.L.polr_mpx_run_many(hs, None, b.ctypes.data, e.ctypes.data, n, out.h if out else None))
+
+
+def _stats_dict(st, P, k):
+    return {"num_tuples_processed": st.num_tuples_processed, "num_intermediates": st.num_intermediates,
+            "num_rounds": st.num_rounds,
+            "input_tuple_count_per_path": [st.input_tuple_count_per_path[i] for i in range(P)],
+            "path_resistances": [st.path_resistances[i] for i in range(P)],
+            "stage_out": [[st.stage_out[i][j] for j in range(k)] for i in range(P)]}
+
+
+def finish_many(mpxs):
+    n = len(mpxs)
+    hs = (C.c_void_p * n)(*[m.h for m in mpxs])
+    stats = (MpxStats * n)()
+    ctx = mpxs[0].ctx
+    ctx.check(ctx.L.polr_mpx_finish_many(hs, n, stats))
+    return [_stats_dict(stats[i], mpxs[i].pipe.n_paths, mpxs[i].pipe.k) for i in range(n)]
 
 
 def build_joins(ctx, wl):

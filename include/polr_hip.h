@@ -237,6 +237,13 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 /* Route and probe source chunks [chunk_begin, chunk_end) (chunk c = tuples [c*chunk_size, ...)
  * unless chunk offsets were set) entirely on the device; asynchronous. */
 int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out);
+/* Several executors at once: ms[i] routes chunks [chunk_begin[i], chunk_end[i]) with its own multiplexer
+ * state on its own stream (streams may be NULL: every multiplexer owns one) -- the counterpart of the
+ * reference's worker threads, one PipelineExecutor + MultiplexerState each (pipeline.cpp:145-174,
+ * pipeline_executor.cpp:28-41).  One host thread pumps all of them, so their routing rounds overlap on the
+ * device.  All multiplexers must belong to the same pipeline; `out` (may be NULL) is shared. */
+int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin, const uint64_t *chunk_end,
+                      uint32_t n, polr_out *out);
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
 /* fresh MultiplexerState (a new PipelineExecutor / a new pass over the source) */
 int polr_mpx_reset(polr_mpx *m, void *stream);
@@ -246,6 +253,8 @@ int polr_mpx_enable_timing(polr_mpx *m, int enable);
 int polr_mpx_kernel_time(polr_mpx *m, double *total_ms, uint64_t *n_launches);
 /* PushFinalize's last FinalizePathRun (polar_pipeline_executor.cpp:150-151) + read back */
 int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats);
+/* the same for every executor of a polr_mpx_run_many (on the streams the runs used); stats[n] */
+int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats);
 int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tuples, uint64_t *intermediates,
                        uint64_t max_rounds, uint64_t *n_rounds);
 void polr_mpx_destroy(polr_mpx *m);
