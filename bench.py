@@ -161,6 +161,10 @@ def main():
                          "contiguous share of the source chunks on its own HIP stream -- the counterpart of the "
                          "reference's worker threads (one PipelineExecutor + MultiplexerState per thread, "
                          "pipeline.cpp:145-174); 1 = the single-executor trace the parity tests pin")
+    ap.add_argument("--launch", default="resident", choices=["resident", "rounds"],
+                    help="resident: the whole pass is ONE cooperative launch (device-resident routing loop, "
+                         "polr_mpx_run_resident); rounds: one self-routing launch per routing round "
+                         "(polr_mpx_run / _run_many)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -260,6 +264,11 @@ def main():
     ranges = [(x[2], x[3]) for x in execs]
 
     def step():
+        if args.launch == "resident":
+            # fresh multiplexer states, the whole pass and the closing FinalizePathRun: one launch
+            capi.run_resident(mpxs, ranges, reset=True, finish=True)
+            results[:] = capi.finish_many(mpxs)
+            return results
         for m in mpxs:
             m.reset()
         if E == 1:
@@ -357,7 +366,7 @@ def main():
                                     joins_info[1]["n_rows"]) if args.workload == "job_light_01" else args.workload,
                        "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
-                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E},
+                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch},
             "total_intermediates": int(st["num_intermediates"]),
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],

@@ -121,6 +121,14 @@ extern "C++" void polr_launch_reduce_counts(hipStream_t stream, const unsigned l
 DECL_K(2)
 DECL_K(4)
 DECL_K(8)
+#define DECL_RES_K(KK)                                                                                                 \
+	int polr_resident_occupancy_k##KK(uint32_t W, uint32_t waves_per_block);                                          \
+	hipError_t polr_launch_resident_kernel_k##KK(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,             \
+	                                             hipStream_t stream, const DevPipeline *pipe,                        \
+	                                             const ResidentExec *execs, uint32_t n_exec, DevOut out);
+DECL_RES_K(2)
+DECL_RES_K(4)
+DECL_RES_K(8)
 
 static uint32_t compiled_k(uint32_t k) {
 	return k <= 2 ? 2 : (k <= 4 ? 4 : 8);
@@ -163,5 +171,29 @@ extern "C++" hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t
 	default:
 		return polr_launch_path_kernel_k8(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
 		                                  unit_sizes, out, counts, sr);
+	}
+}
+
+extern "C++" int polr_resident_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block) {
+	switch (compiled_k(k)) {
+	case 2:
+		return polr_resident_occupancy_k2(W, waves_per_block);
+	case 4:
+		return polr_resident_occupancy_k4(W, waves_per_block);
+	default:
+		return polr_resident_occupancy_k8(W, waves_per_block);
+	}
+}
+
+extern "C++" hipError_t polr_launch_resident_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
+                                                    hipStream_t stream, const DevPipeline *pipe,
+                                                    const ResidentExec *execs, uint32_t n_exec, DevOut out) {
+	switch (compiled_k(k)) {
+	case 2:
+		return polr_launch_resident_kernel_k2(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
+	case 4:
+		return polr_launch_resident_kernel_k4(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
+	default:
+		return polr_launch_resident_kernel_k8(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
 	}
 }

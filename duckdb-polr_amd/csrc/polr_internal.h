@@ -116,6 +116,10 @@ hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, ui
                                    hipStream_t stream, const DevPipeline *pipe, const DevRound *rounds,
                                    const uint64_t *unit_prefix, uint32_t n_rounds, const uint32_t *unit_sizes,
                                    DevOut out, unsigned long long *counts, SelfRoute sr);
+int polr_resident_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block);
+hipError_t polr_launch_resident_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
+                                       hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
+                                       uint32_t n_exec, DevOut out);
 void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,

@@ -47,6 +47,14 @@ struct polr_mpx {
 	int poll_batch = 8;
 	uint32_t wide0_mask = 0;
 	uint64_t n_chunks = 0;
+	// resident launches
+	ResidentSync *sync_dev = nullptr;
+	ResidentExec *execs_dev = nullptr; // (owned by the first multiplexer of a resident run)
+	uint32_t execs_cap = 0;
+	uint32_t res_epoch = 0;
+	polr_mpx_stats *stats_host = nullptr; // pinned, mapped: closing statistics of a POLR_RUN_FINISH run
+	polr_mpx_stats *stats_host_dev = nullptr;
+	bool stats_in_host = false;
 	// optional per-launch timing (measurement only)
 	bool timing = false;
 	std::vector<hipEvent_t> ev_start, ev_stop;
@@ -54,6 +62,24 @@ struct polr_mpx {
 	double timed_ms = 0;
 	uint64_t timed_launches = 0;
 };
+
+// every multiplexer keeps its work on ONE stream at a time: the caller's, else the stream of its last run
+// (a resident run puts all its executors on one stream), else its own
+static hipStream_t pick_stream(polr_mpx *m, void *stream) {
+	return stream ? (hipStream_t)stream : (m->last_stream ? m->last_stream : m->own_stream);
+}
+
+// move a multiplexer onto `st`: whatever it still has queued elsewhere must be finished first
+static hipError_t adopt_stream(polr_mpx *m, hipStream_t st) {
+	const hipStream_t prev = m->last_stream ? m->last_stream : m->own_stream;
+	hipError_t e = hipSuccess;
+	if (prev != st) {
+		e = hipStreamSynchronize(prev);
+		m->pending_sync = false;
+	}
+	m->last_stream = st;
+	return e;
+}
 
 static void drain_events(polr_mpx *m) {
 	for (size_t i = 0; i < m->ev_used; i++) {
@@ -71,6 +97,9 @@ __global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_
                                      uint64_t *log_inter, uint32_t wide0_mask, volatile uint32_t *progress,
                                      uint32_t steps_done_init) {
 	m->wide0_mask = wide0_mask;
+	m->cfg = cfg;
+	m->n_paths = n_paths;
+	m->pad4 = 0;
 	m->pad2 = 0;
 	m->progress = progress;
 	m->steps_done = steps_done_init; // monotonic across resets: the host throttles on differences
@@ -138,25 +167,10 @@ __global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, ui
 	if (lane == 0) {
 		core.AddNumIntermediates(s);
 		m->num_intermediates_total += s;
-		if (!core.first_mpx_run) {
-			const uint64_t path = core.current_path_idx, tuples = core.current_path_tuple_count;
-			const uint64_t closed = core.FinalizePathRun();
-			log_round(m, path, tuples, closed);
-			// a finalized run must not be finalized twice if the caller keeps routing afterwards
-			core.current_path_tuple_count = 0;
-		}
-		stats->num_tuples_processed = core.num_tuples_processed;
-		stats->num_intermediates = m->num_intermediates_total;
-		stats->num_rounds = m->num_rounds;
+		polr_close_run(m);
 	}
 	__syncthreads();
-	for (uint32_t i = lane; i < POLR_MAX_PATHS; i += 64) {
-		stats->input_tuple_count_per_path[i] = i < core.path_count ? core.input_tuple_count_per_path[i] : 0;
-		stats->path_resistances[i] = i < core.path_count ? core.path_resistances[i] : 0;
-	}
-	for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
-		stats->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = m->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS];
-	}
+	polr_write_stats(m, m, stats, lane);
 }
 
 extern "C" {
@@ -199,6 +213,10 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 		e = hipHostGetDevicePointer((void **)&m->progress_dev, m->done_host, 0);
 	}
 	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->sync_dev, sizeof(ResidentSync)) : e;
+	e = e == hipSuccess ? hipHostMalloc((void **)&m->stats_host, sizeof(polr_mpx_stats), hipHostMallocMapped) : e;
+	e = e == hipSuccess ? hipHostGetDevicePointer((void **)&m->stats_host_dev, m->stats_host, 0) : e;
+	e = e == hipSuccess ? hipMemset(m->sync_dev, 0, sizeof(ResidentSync)) : e;
 	if (e != hipSuccess) {
 		polr_mpx_destroy(m);
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer allocation failed: %s", hipGetErrorString(e));
@@ -273,6 +291,7 @@ static int run_begin(RunState &rs, polr_mpx *m, void *stream, uint64_t chunk_beg
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
+	HIPCHK(ctx, adopt_stream(m, st));
 	const bool materialize = out != nullptr;
 	uint32_t unit_unused, max_blocks;
 	int rc = polr_plan_launch(p, materialize, p->n_tuples, &unit_unused, &max_blocks);
@@ -291,6 +310,7 @@ static int run_begin(RunState &rs, polr_mpx *m, void *stream, uint64_t chunk_beg
 	max_blocks = std::max<uint32_t>(max_blocks / std::max<uint32_t>(share, 1), 64);
 	rs.m = m;
 	rs.st = st;
+	m->stats_in_host = false;
 	memset(&rs.dout, 0, sizeof(rs.dout));
 	if (out) {
 		rs.dout = out->dev;
@@ -303,7 +323,7 @@ static int run_begin(RunState &rs, polr_mpx *m, void *stream, uint64_t chunk_beg
 	rs.max_blocks = max_blocks;
 	rs.wpb = wpb;
 	if (m->pending_sync) { // a previous run left launches queued: settle before reading progress
-		HIPCHK(ctx, hipStreamSynchronize(m->last_stream ? m->last_stream : st));
+		HIPCHK(ctx, hipStreamSynchronize(st));
 		m->pending_sync = false;
 	}
 	hipLaunchKernelGGL(polr_mpx_set_range_kernel, dim3(1), dim3(1), 0, st, m->dev, chunk_begin, chunk_end,
@@ -415,17 +435,150 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
 	return rc;
 }
 
+// The whole run in ONE cooperative launch: every executor gets a slice of the grid (its router workgroup +
+// probe workgroups), routing decisions never leave the device, the host only enqueues.  Asynchronous:
+// polr_mpx_finish / _finish_many synchronise.
+int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
+                          uint32_t n, polr_out *out, uint32_t flags) {
+	if (!ms || !chunk_begin || !chunk_end || n == 0 || !ms[0]) {
+		return POLR_E_INVALID;
+	}
+	polr_mpx *m0 = ms[0];
+	polr_pipeline *p = m0->pipe;
+	polr_ctx *ctx = p->ctx;
+	if (n > 64) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "at most 64 executors per resident run");
+	}
+	if (p->n_tuples >= 0xFFFFFFF0ull) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "resident run: source partition too large");
+	}
+	if (out && out->pipe != p) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "output object belongs to another pipeline");
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		if (!ms[i] || ms[i]->pipe != p) {
+			return POLR_E_INVALID;
+		}
+		for (uint32_t j = 0; j < i; j++) {
+			if (ms[j] == ms[i]) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "the same multiplexer twice in one resident run");
+			}
+		}
+		if (chunk_begin[i] > chunk_end[i] || chunk_end[i] > ms[i]->n_chunks) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks",
+			          (unsigned long long)chunk_begin[i], (unsigned long long)chunk_end[i],
+			          (unsigned long long)ms[i]->n_chunks);
+		}
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = stream ? (hipStream_t)stream : m0->own_stream;
+	const bool materialize = out != nullptr;
+	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
+	const uint32_t wpb = polr_waves_per_block(p, materialize);
+	if (wpb == 0) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
+	}
+	int occ = polr_resident_occupancy(dp.k, dp.W, wpb);
+	if (occ < 1) {
+		POLR_FAIL(ctx, POLR_E_HIP, "resident kernel does not fit on a CU");
+	}
+	occ = std::min(occ, 8);
+	// grid: a multiple of n, at least router + one worker workgroup per executor, never more than is co-resident
+	const uint32_t capacity = (uint32_t)ctx->n_cus * (uint32_t)occ;
+	uint32_t per_exec = capacity / n;
+	if (per_exec < 2) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "%u executors do not fit on the device at once", n);
+	}
+	const uint32_t n_blocks = per_exec * n;
+	for (uint32_t i = 0; i < n; i++) {
+		HIPCHK(ctx, adopt_stream(ms[i], st));
+		if (ms[i]->pending_sync) {
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			ms[i]->pending_sync = false;
+		}
+	}
+	if (m0->execs_cap < n) {
+		if (m0->execs_dev) {
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			hipFree(m0->execs_dev);
+			m0->execs_dev = nullptr;
+		}
+		HIPCHK(ctx, hipMalloc((void **)&m0->execs_dev, (size_t)std::max<uint32_t>(n, 8) * sizeof(ResidentExec)));
+		m0->execs_cap = std::max<uint32_t>(n, 8);
+	}
+	std::vector<ResidentExec> ex(n);
+	for (uint32_t i = 0; i < n; i++) {
+		polr_mpx *m = ms[i];
+		m->res_epoch = (m->res_epoch + 1) & 0xFFFu;
+		ex[i].mpx = m->dev;
+		ex[i].sync = m->sync_dev;
+		ex[i].counts = m->counts_dev;
+		ex[i].chunk_begin = chunk_begin[i];
+		ex[i].chunk_end = chunk_end[i];
+		ex[i].chunk_offsets = m->chunk_offsets_dev;
+		ex[i].n_chunks = m->n_chunks;
+		ex[i].n_tuples = p->n_tuples;
+		ex[i].epoch = m->res_epoch;
+		ex[i].flags = flags;
+		ex[i].stats_out = m->stats_host_dev;
+		m->stats_in_host = (flags & POLR_RUN_FINISH) != 0;
+		ex[i].stamps = nullptr;
+#ifdef POLR_DIAG_STAMPS
+		if (!m->stamps_dev) {
+			HIPCHK(ctx, hipMalloc((void **)&m->stamps_dev, 4096 * 8 * 8));
+		}
+		HIPCHK(ctx, hipMemsetAsync(m->stamps_dev, 0, 4096 * 8 * 8, st));
+		ex[i].stamps = m->stamps_dev;
+#endif
+		((volatile uint32_t *)m->done_host)[1] = 0;
+	}
+	// (pageable source: staged by the runtime before the call returns)
+	HIPCHK(ctx, hipMemcpyAsync(m0->execs_dev, ex.data(), (size_t)n * sizeof(ResidentExec), hipMemcpyHostToDevice, st));
+	DevOut dout;
+	memset(&dout, 0, sizeof(dout));
+	if (out) {
+		dout = out->dev;
+		out->stats_valid = false;
+	}
+	size_t ev = 0;
+	if (m0->timing) {
+		ev = m0->ev_used++;
+		if (ev >= m0->ev_start.size()) {
+			hipEvent_t a, b;
+			HIPCHK(ctx, hipEventCreate(&a));
+			HIPCHK(ctx, hipEventCreate(&b));
+			m0->ev_start.push_back(a);
+			m0->ev_stop.push_back(b);
+		}
+		HIPCHK(ctx, hipEventRecord(m0->ev_start[ev], st));
+	}
+	hipError_t e = polr_launch_resident_kernel(dp.W, dp.k, n_blocks, wpb, st, materialize ? p->dev_mat : p->dev_count,
+	                                           m0->execs_dev, n, dout);
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "resident kernel launch failed: %s", hipGetErrorString(e));
+	}
+	if (m0->timing) {
+		HIPCHK(ctx, hipEventRecord(m0->ev_stop[ev], st));
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		ms[i]->pending_sync = true;
+	}
+	return POLR_OK;
+}
+
 int polr_mpx_reset(polr_mpx *m, void *stream) {
 	if (!m) {
 		return POLR_E_INVALID;
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
+	hipStream_t st = pick_stream(m, stream);
+	HIPCHK(ctx, adopt_stream(m, st));
 	if (m->pending_sync) { // launches of the previous pass may still be queued on its stream
 		HIPCHK(ctx, hipStreamSynchronize(st));
 		m->pending_sync = false;
 	}
+	m->stats_in_host = false;
 	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8, st));
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
 	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask,
@@ -465,18 +618,29 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
-	if (!m->stats_dev) {
-		HIPCHK(ctx, hipMalloc((void **)&m->stats_dev, sizeof(polr_mpx_stats)));
+	hipStream_t st = pick_stream(m, stream);
+	HIPCHK(ctx, adopt_stream(m, st));
+	hipError_t e = hipSuccess;
+	if (m->stats_in_host) { // the resident run closed itself: nothing to launch
+		e = hipStreamSynchronize(st);
+		memcpy(stats, m->stats_host, sizeof(polr_mpx_stats));
+	} else {
+		if (!m->stats_dev) {
+			HIPCHK(ctx, hipMalloc((void **)&m->stats_dev, sizeof(polr_mpx_stats)));
+		}
+		hipLaunchKernelGGL(polr_mpx_finish_kernel, dim3(1), dim3(64), 0, st, m->dev, m->counts_dev, m->pipe->k,
+		                   m->stats_dev);
+		e = hipMemcpyAsync(stats, m->stats_dev, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st);
+		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
 	}
-	hipLaunchKernelGGL(polr_mpx_finish_kernel, dim3(1), dim3(64), 0, st, m->dev, m->counts_dev, m->pipe->k,
-	                   m->stats_dev);
-	hipError_t e = hipMemcpyAsync(stats, m->stats_dev, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st);
-	e = e == hipSuccess ? hipStreamSynchronize(st) : e;
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer finish failed: %s", hipGetErrorString(e));
 	}
 	m->pending_sync = false;
+	if (((volatile uint32_t *)m->done_host)[2]) {
+		((volatile uint32_t *)m->done_host)[2] = 0;
+		POLR_FAIL(ctx, POLR_E_HIP, "resident run timed out waiting for its workers (results incomplete)");
+	}
 	if (m->timing) {
 		drain_events(m);
 	}
@@ -494,6 +658,9 @@ int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
 	for (uint32_t i = 0; i < n; i++) {
 		polr_mpx *m = ms[i];
 		hipStream_t st = m->last_stream ? m->last_stream : m->own_stream;
+		if (m->stats_in_host) {
+			continue; // closed inside its resident run
+		}
 		if (!m->stats_dev) {
 			HIPCHK(ctx, hipMalloc((void **)&m->stats_dev, sizeof(polr_mpx_stats)));
 		}
@@ -501,13 +668,29 @@ int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
 		                   m->stats_dev);
 		HIPCHK(ctx, hipMemcpyAsync(&stats[i], m->stats_dev, sizeof(polr_mpx_stats), hipMemcpyDeviceToHost, st));
 	}
+	bool timed_out = false;
+	hipStream_t synced = nullptr;
 	for (uint32_t i = 0; i < n; i++) {
 		polr_mpx *m = ms[i];
-		HIPCHK(ctx, hipStreamSynchronize(m->last_stream ? m->last_stream : m->own_stream));
+		hipStream_t st = m->last_stream ? m->last_stream : m->own_stream;
+		if (st != synced) { // (executors of a resident run share one stream)
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			synced = st;
+		}
+		if (m->stats_in_host) {
+			memcpy(&stats[i], m->stats_host, sizeof(polr_mpx_stats));
+		}
 		m->pending_sync = false;
 		if (m->timing) {
 			drain_events(m);
 		}
+		if (((volatile uint32_t *)m->done_host)[2]) {
+			((volatile uint32_t *)m->done_host)[2] = 0;
+			timed_out = true;
+		}
+	}
+	if (timed_out) {
+		POLR_FAIL(ctx, POLR_E_HIP, "resident run timed out waiting for its workers (results incomplete)");
 	}
 	return POLR_OK;
 }
@@ -519,7 +702,7 @@ int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tupl
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
+	hipStream_t st = pick_stream(m, stream);
 	DevMpx h;
 	HIPCHK(ctx, hipMemcpyAsync(&h, m->dev, sizeof(DevMpx), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipStreamSynchronize(st));
@@ -584,6 +767,15 @@ void polr_mpx_destroy(polr_mpx *m) {
 	}
 	if (m->done_host) {
 		hipHostFree(m->done_host);
+	}
+	if (m->sync_dev) {
+		hipFree(m->sync_dev);
+	}
+	if (m->stats_host) {
+		hipHostFree(m->stats_host);
+	}
+	if (m->execs_dev) {
+		hipFree(m->execs_dev);
 	}
 	for (auto e : m->ev_start) {
 		hipEventDestroy(e);

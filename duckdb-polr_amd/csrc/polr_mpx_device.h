@@ -33,10 +33,24 @@ struct DevMpx {
 	volatile uint32_t *progress;
 	uint32_t steps_done, pad3;
 	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
+	// cold: what a fresh MultiplexerState is built from (a resident run can reset itself)
+	polr_mpx_config cfg;
+	uint32_t n_paths, pad4;
 };
 
-__device__ __forceinline__ uint64_t chunk_start(const DevMpx *m, uint64_t c) {
+// window of the chunk-offset array kept in LDS by a resident router (the boundaries a routing step needs
+// are then LDS reads instead of a chain of dependent HBM loads)
+#define POLR_OFFS_CACHE 2048
+struct OffsCache {
+	uint64_t base, n; // offsets [base, base + n) are cached
+	uint64_t *data;
+};
+
+__device__ __forceinline__ uint64_t chunk_start(const DevMpx *m, uint64_t c, const OffsCache *oc = nullptr) {
 	if (m->chunk_offsets) {
+		if (oc && c - oc->base < oc->n) {
+			return oc->data[c - oc->base];
+		}
 		return m->chunk_offsets[c];
 	}
 	const uint64_t s = c * (uint64_t)m->chunk_size;
@@ -81,7 +95,8 @@ __device__ __forceinline__ void polr_publish_progress(DevMpx *m) {
 __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, DevRound *round,
                                                       uint64_t *unit_prefix, uint32_t *unit_size_out,
                                                       unsigned long long *counts, uint32_t k, uint32_t resident_waves,
-                                                      uint32_t lane, bool coherent);
+                                                      uint32_t lane, bool coherent, const OffsCache *oc = nullptr,
+                                                      bool discard = false);
 // Executed by ONE full wave (lane = 0..63).  `coherent`: the counters were just written by other
 // workgroups of the same launch -> read them with device-scope atomics (exchange with 0).
 __device__ __forceinline__ void polr_router_step(DevMpx *mg, DevRound *round, uint64_t *unit_prefix,
@@ -115,7 +130,7 @@ __device__ __forceinline__ void polr_router_step(DevMpx *mg, DevRound *round, ui
 __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, DevRound *round,
                                                       uint64_t *unit_prefix, uint32_t *unit_size_out,
                                                       unsigned long long *counts, uint32_t k, uint32_t resident_waves,
-                                                      uint32_t lane, bool coherent) {
+                                                      uint32_t lane, bool coherent, const OffsCache *oc, bool discard) {
 	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487).
 	// One wave: lane s sums shard s of the k counters, a shuffle tree adds the shards, lane 0 routes.
 	uint64_t s = 0;
@@ -137,12 +152,17 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 				v += __shfl_down(v, d, 32);
 			}
 			const unsigned long long v_hi = __shfl(v, 32, 64);
-			if (lane == 0) {
+			if (lane == 0 && !discard) {
+				// (fire-and-forget adds: a load-add-store here would put an HBM round trip on the routing path)
 				s += v;
-				mg->stage_out[m->last_path][j0] += v;
+				if (v) {
+					atomicAdd((unsigned long long *)&mg->stage_out[m->last_path][j0], v);
+				}
 				if (j0 + 1 < k) {
 					s += v_hi;
-					mg->stage_out[m->last_path][j0 + 1] += v_hi;
+					if (v_hi) {
+						atomicAdd((unsigned long long *)&mg->stage_out[m->last_path][j0 + 1], v_hi);
+					}
 				}
 			}
 		}
@@ -171,8 +191,8 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 		// the window continues (a previous run() ended inside it): whole chunks bypass routing
 		const uint64_t left = m->chunk_end - m->chunk_idx;
 		const uint64_t n = core.num_cache_flushing_skips < left ? core.num_cache_flushing_skips : left;
-		begin = chunk_start(m, m->chunk_idx);
-		tuples = chunk_start(m, m->chunk_idx + n) - begin;
+		begin = chunk_start(m, m->chunk_idx, oc);
+		tuples = chunk_start(m, m->chunk_idx + n, oc) - begin;
 		core.IncreaseInputTupleCount(tuples);
 		if (core.num_cache_flushing_skips != polr::kIdxMax) {
 			core.num_cache_flushing_skips -= n;
@@ -180,8 +200,8 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 		m->chunk_idx += n;
 		path = core.current_path_idx;
 	} else {
-		const uint64_t c0 = chunk_start(m, m->chunk_idx);
-		const uint64_t size = chunk_start(m, m->chunk_idx + 1) - c0;
+		const uint64_t c0 = chunk_start(m, m->chunk_idx, oc);
+		const uint64_t size = chunk_start(m, m->chunk_idx + 1, oc) - c0;
 		const uint64_t prev_path = core.current_path_idx;
 		const uint64_t prev_tuples = core.current_path_tuple_count;
 		bool finalized;
@@ -198,7 +218,7 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 			if (core.num_cache_flushing_skips > 0 && m->chunk_idx < m->chunk_end) {
 				const uint64_t left = m->chunk_end - m->chunk_idx;
 				const uint64_t n = core.num_cache_flushing_skips < left ? core.num_cache_flushing_skips : left;
-				const uint64_t extra = chunk_start(m, m->chunk_idx + n) - chunk_start(m, m->chunk_idx);
+				const uint64_t extra = chunk_start(m, m->chunk_idx + n, oc) - chunk_start(m, m->chunk_idx, oc);
 				core.IncreaseInputTupleCount(extra);
 				if (core.num_cache_flushing_skips != polr::kIdxMax) {
 					core.num_cache_flushing_skips -= n;
@@ -226,3 +246,262 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 	polr_publish_progress(m);
 }
 
+
+// ==== resident launch: one kernel routes and probes a whole run ======================================
+// Executors (multiplexer + its share of the source chunks) are laid over the grid by blockIdx % n_exec,
+// which is also how the hardware deals workgroups to the 8 XCDs: with 8 executors every executor lives on
+// its own XCD and its sync words stay in that XCD's L2.  Workgroup 0 of an executor is its router (one
+// wave, multiplexer state in LDS for the whole run); the other workgroups are probe workers.  Router and
+// workers talk through two tagged 64-bit words and one arrival counter, all with relaxed agent-scope
+// atomics -- no fences, no host.
+//
+//   word_a = epoch:12 | round:20 | count:32     count = tuples of the round; POLR_RES_DONE = run over
+//   word_b = tag:14 | emit:1 | path:5 | unit_size:12 | begin:32     tag = (epoch & 127) << 7 | (round & 127)
+//
+// A worker waits for word_a to show its epoch and a round number other than the one it processed last,
+// then for word_b to carry the matching tag (the two stores need no order).  Units of a round are dealt
+// statically (unit u -> worker u mod n_workers), so only workers that own a unit of the round touch
+// anything else; they add the units they finished to `units_done` after their counter atomics have
+// returned.  The router waits for units_done to reach the running total, absorbs the counters, routes.
+#define POLR_RES_DONE 0xFFFFFFFFu
+#define POLR_RES_TIMEOUT_TICKS 400000000ull // 4 s of the 100 MHz wall clock: a wait this long is a lost run
+
+#define POLR_RES_COPIES 64 // the round words are published in 64 copies (one per router lane, own cache line)
+#define POLR_RES_ARRIVE 32 // arrival counter shards (own cache line each)
+struct ResidentSync {
+	struct {
+		unsigned long long a, b, pad[6];
+	} pub[POLR_RES_COPIES]; // workgroup w polls copy w % 64: a few pollers per line instead of a thousand
+	struct {
+		unsigned long long v, pad[7];
+	} arrived[POLR_RES_ARRIVE]; // monotonic across runs; the router sums the shards
+};
+
+struct ResidentExec {
+	DevMpx *mpx;
+	ResidentSync *sync;
+	unsigned long long *counts;
+	uint64_t chunk_begin, chunk_end;
+	const uint64_t *chunk_offsets;
+	uint64_t n_chunks, n_tuples;
+	uint32_t epoch; // 12 bits, host-incremented per run
+	uint32_t flags; // POLR_RUN_RESET | POLR_RUN_FINISH
+	polr_mpx_stats *stats_out; // POLR_RUN_FINISH: where the closing statistics go (pinned host memory)
+	unsigned long long *stamps; // diagnostic builds only (POLR_DIAG_STAMPS), else nullptr
+};
+
+#ifdef POLR_DIAG_STAMPS
+#define RES_STAMP(x_, round_, i_)                                                                                      \
+	if ((x_).stamps && (round_) < 1024) {                                                                              \
+		(x_).stamps[(uint64_t)(round_) * 8 + (i_)] = wall_clock64();                                                   \
+	}
+#else
+#define RES_STAMP(x_, round_, i_)
+#endif
+
+#define POLR_RES_HOT_DWORDS (offsetof(DevMpx, stage_out) / 4)
+#define POLR_RES_ROUTER_DWORDS (POLR_RES_HOT_DWORDS + 16)
+
+__device__ __forceinline__ unsigned long long polr_res_word_a(uint32_t epoch, uint32_t round, uint32_t count) {
+	return ((unsigned long long)(epoch & 0xFFFu) << 52) | ((unsigned long long)(round & 0xFFFFFu) << 32) | count;
+}
+__device__ __forceinline__ uint32_t polr_res_tag(uint32_t epoch, uint32_t round) {
+	return ((epoch & 127u) << 7) | (round & 127u);
+}
+__device__ __forceinline__ uint32_t polr_res_next_round(uint32_t round) {
+	round = (round + 1) & 0xFFFFFu;
+	return round == 0 ? 1 : round; // 0 is the workers' "nothing seen yet"
+}
+
+// PushFinalize's closing FinalizePathRun (polar_pipeline_executor.cpp:150-151); lane 0 of the caller,
+// counters already absorbed.  m: the state being worked on (LDS copy or HBM)
+__device__ __forceinline__ void polr_close_run(DevMpx *m) {
+	polr::MultiplexerCore &core = m->core;
+	if (!core.first_mpx_run) {
+		const uint64_t path = core.current_path_idx, tuples = core.current_path_tuple_count;
+		const uint64_t closed = core.FinalizePathRun();
+		log_round(m, path, tuples, closed);
+		// a finalized run must not be finalized twice if the caller keeps routing afterwards
+		core.current_path_tuple_count = 0;
+	}
+}
+
+// one wave; m: hot state (LDS copy or HBM), mg: the HBM object (stage_out)
+__device__ __forceinline__ void polr_write_stats(const DevMpx *m, DevMpx *mg, polr_mpx_stats *stats, uint32_t lane) {
+	const polr::MultiplexerCore &core = m->core;
+	if (lane == 0) {
+		stats->num_tuples_processed = core.num_tuples_processed;
+		stats->num_intermediates = m->num_intermediates_total;
+		stats->num_rounds = m->num_rounds;
+	}
+	for (uint32_t i = lane; i < POLR_MAX_PATHS; i += 64) {
+		stats->input_tuple_count_per_path[i] = i < core.path_count ? core.input_tuple_count_per_path[i] : 0;
+		stats->path_resistances[i] = i < core.path_count ? core.path_resistances[i] : 0;
+	}
+	for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
+		stats->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = __hip_atomic_load(
+		    (unsigned long long *)&mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS], __ATOMIC_RELAXED,
+		    __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+// sum of the arrival shards, the same value in every lane (full wave)
+__device__ __forceinline__ unsigned long long polr_res_arrived(ResidentSync *sync, uint32_t lane) {
+	unsigned long long v = 0;
+	if (lane < POLR_RES_ARRIVE) {
+		v = __hip_atomic_load(&sync->arrived[lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	for (int d = 16; d > 0; d >>= 1) {
+		v += __shfl_xor(v, d, 64);
+	}
+	return __shfl(v, 0, 64);
+}
+
+// (re)load the LDS window of chunk boundaries starting at chunk `from`; full wave
+__device__ __forceinline__ void polr_offs_cache_fill(OffsCache &oc, const ResidentExec &x, uint64_t from,
+                                                     uint32_t cap, uint32_t lane) {
+	uint64_t n = x.n_chunks + 1 - from; // entries [from, n_chunks] exist
+	if (from > x.n_chunks) {
+		n = 0;
+	}
+	if (n > cap) {
+		n = cap;
+	}
+	__builtin_amdgcn_wave_barrier();
+	for (uint64_t i = lane; i < n; i += 64) {
+		oc.data[i] = x.chunk_offsets[from + i];
+	}
+	__builtin_amdgcn_wave_barrier();
+	oc.base = from;
+	oc.n = n;
+}
+
+// The router of one executor: ONE full wave, for the whole run.  lds: POLR_RES_ROUTER_DWORDS dwords.
+// cache_lds / cache_cap: the router workgroup's (otherwise unused) dynamic LDS, in 8-byte entries.
+__device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint32_t k, uint32_t n_workers,
+                                                     uint32_t lane, uint32_t *lds, uint64_t *cache_lds,
+                                                     uint32_t cache_cap) {
+	DevMpx *mg = x.mpx;
+	{
+		const uint32_t *src = (const uint32_t *)mg;
+		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+			lds[i] = src[i];
+		}
+	}
+	DevMpx *m = (DevMpx *)lds;
+	DevRound *round = (DevRound *)(lds + POLR_RES_HOT_DWORDS); // 24 bytes
+	uint64_t *prefix = (uint64_t *)(lds + POLR_RES_HOT_DWORDS + 8);
+	uint32_t *us = lds + POLR_RES_HOT_DWORDS + 12;
+	OffsCache oc;
+	oc.base = 0;
+	oc.n = 0;
+	oc.data = cache_lds;
+	if (cache_cap > POLR_OFFS_CACHE) {
+		cache_cap = POLR_OFFS_CACHE;
+	}
+	const bool reset = (x.flags & POLR_RUN_RESET) != 0;
+	if (reset) {
+		// a fresh MultiplexerState (what polr_mpx_reset does between passes), without a launch of its own
+		for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
+			mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = 0;
+		}
+		if (lane == 0) {
+			const polr_mpx_config cfg = mg->cfg;
+			m->core.Init(cfg.routing, mg->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
+			m->num_intermediates_total = 0;
+			m->num_rounds = 0;
+			m->n_log = 0;
+			m->last_path = 0;
+		}
+	}
+	if (lane == 0) {
+		// what polr_mpx_set_range_kernel does for a per-round run
+		m->chunk_idx = x.chunk_begin;
+		m->chunk_end = x.chunk_end;
+		m->chunk_offsets = x.chunk_offsets;
+		m->n_chunks = x.n_chunks;
+		m->n_tuples = x.n_tuples;
+		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
+	}
+	unsigned long long target = polr_res_arrived(x.sync, lane);
+	uint32_t round_no = 0;
+	uint32_t n_steps = 0;
+	while (true) {
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) {
+			RES_STAMP(x, n_steps, 0)
+		}
+		if (x.chunk_offsets && n_steps == 0) {
+			polr_offs_cache_fill(oc, x, x.chunk_begin, cache_cap, lane);
+		}
+		// (a reset run drops whatever the counters still hold: first step only)
+		polr_router_step_impl(m, mg, round, prefix, us, x.counts, k, n_workers, lane, true, &oc, reset && n_steps == 0);
+		__builtin_amdgcn_wave_barrier();
+		// (all lanes read what lane 0 left in LDS)
+		round_no = polr_res_next_round(round_no);
+		const bool done = ((volatile DevMpx *)m)->done != 0;
+		if (done) {
+			__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, POLR_RES_DONE), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+			break;
+		}
+		const volatile DevRound *vr = round;
+		const unsigned long long bw = (unsigned long long)(uint32_t)vr->begin |
+		                              ((unsigned long long)(((volatile uint32_t *)us)[0] & 0xFFFu) << 32) |
+		                              ((unsigned long long)(vr->path & 31u) << 44) |
+		                              ((unsigned long long)(vr->emit & 1u) << 49) |
+		                              ((unsigned long long)polr_res_tag(x.epoch, round_no) << 50);
+		__hip_atomic_store(&x.sync->pub[lane].b, bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, (uint32_t)vr->count),
+		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		target += ((volatile uint64_t *)prefix)[1];
+		if (lane == 0) {
+			RES_STAMP(x, n_steps, 1)
+		}
+		// while the workers probe: keep the boundaries of the chunks ahead in LDS
+		{
+			const uint64_t ci = ((volatile DevMpx *)m)->chunk_idx;
+			if (x.chunk_offsets && ci - oc.base >= oc.n / 2) {
+				polr_offs_cache_fill(oc, x, ci, cache_cap, lane);
+			}
+		}
+		const unsigned long long t0 = wall_clock64();
+		bool lost = false;
+		while (polr_res_arrived(x.sync, lane) != target) {
+			__builtin_amdgcn_s_sleep(1);
+			if (wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
+				lost = true;
+				break;
+			}
+		}
+		if (lane == 0) {
+			RES_STAMP(x, n_steps, 2)
+		}
+		n_steps++;
+		if (lost) {
+			// a worker is missing: release everybody and report (host: progress word 2)
+			__hip_atomic_store(&x.sync->pub[lane].a,
+			                   polr_res_word_a(x.epoch, polr_res_next_round(round_no), POLR_RES_DONE), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+			if (lane == 0 && m->progress) {
+				m->progress[2] = 1;
+			}
+			break;
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (x.flags & POLR_RUN_FINISH) {
+		if (lane == 0) {
+			polr_close_run(m);
+		}
+		__builtin_amdgcn_wave_barrier();
+		polr_write_stats(m, mg, x.stats_out, lane);
+	}
+	__builtin_amdgcn_wave_barrier();
+	{
+		uint32_t *dst = (uint32_t *)mg;
+		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+			dst[i] = lds[i];
+		}
+	}
+}

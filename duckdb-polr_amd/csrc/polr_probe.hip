@@ -696,6 +696,162 @@ __device__ __forceinline__ void flush_counts(WaveCtx<W, K> &c, unsigned long lon
 	}
 }
 
+#ifdef POLR_RESIDENT_KERNEL
+// ---- resident launch: the whole run in one kernel (protocol: polr_mpx_device.h) ------------------------
+// Workgroup layout: executor = blockIdx % n_exec, workgroup-in-executor = blockIdx / n_exec; workgroup 0 of
+// an executor routes, the others probe.  Worker waves keep their pipeline state (queues, partially filled
+// output chunk) across rounds; between rounds a workgroup sleeps on its barrier while its first thread polls.
+template <int W, int K>
+__global__ __launch_bounds__(256) void polr_resident_kernel(const DevPipeline *__restrict__ pipe,
+                                                            const ResidentExec *__restrict__ execs, uint32_t n_exec,
+                                                            DevOut out) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	__shared__ __attribute__((aligned(16))) uint32_t router_lds[POLR_RES_ROUTER_DWORDS];
+	__shared__ unsigned long long bcast[2][2];
+	const uint32_t wave_in_block = threadIdx.x >> 6;
+	const uint32_t wpb = blockDim.x >> 6;
+	const uint32_t e = blockIdx.x % n_exec;
+	const uint32_t b = blockIdx.x / n_exec;
+	const uint32_t n_wblocks = gridDim.x / n_exec - 1; // host: grid is a multiple of n_exec, >= 2 per executor
+	const uint32_t n_workers = n_wblocks * wpb;
+	const uint32_t k = uni(pipe->k);
+	ResidentExec x;
+	{
+		const ResidentExec *xp = execs + e;
+		x.mpx = (DevMpx *)uni64((uint64_t)xp->mpx);
+		x.sync = (ResidentSync *)uni64((uint64_t)xp->sync);
+		x.counts = (unsigned long long *)uni64((uint64_t)xp->counts);
+		x.chunk_begin = uni64(xp->chunk_begin);
+		x.chunk_end = uni64(xp->chunk_end);
+		x.chunk_offsets = (const uint64_t *)uni64((uint64_t)xp->chunk_offsets);
+		x.n_chunks = uni64(xp->n_chunks);
+		x.n_tuples = uni64(xp->n_tuples);
+		x.epoch = uni(xp->epoch);
+		x.flags = uni(xp->flags);
+		x.stats_out = (polr_mpx_stats *)uni64((uint64_t)xp->stats_out);
+		x.stamps = (unsigned long long *)uni64((uint64_t)xp->stamps);
+	}
+	if (b == 0) {
+		if (wave_in_block == 0) {
+			const uint32_t dyn_dwords = wpb * (K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64);
+			polr_resident_router(x, k, n_workers, threadIdx.x & 63, router_lds, (uint64_t *)lds, dyn_dwords / 2);
+		}
+		return;
+	}
+	const uint32_t per_wave = K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64;
+	WaveCtx<W, K> c;
+	c.k = k;
+	c.lane = threadIdx.x & 63;
+	uint32_t *base = lds + wave_in_block * per_wave;
+	c.desc = (StageDesc *)base;
+	c.q = base + K * STAGE_DESC_DWORDS;
+	c.pend_start = c.q + qtotal<W, K>();
+	c.pend_pref = c.pend_start + K * 64;
+	c.batch0 = c.pend_pref + K * 64;
+#pragma unroll
+	for (int p = 0; p < K; p++) {
+		c.qsize[p] = c.pend_T[p] = c.pend_cur[p] = c.pend_base[p] = c.cnt[p] = 0;
+	}
+	c.sel = uniptr(pipe->sel);
+	c.in_pos = c.in_end = 0;
+	c.wide0 = false;
+	c.flush_token = 0;
+	c.out = out;
+	c.emit = false;
+	c.cur_chunk = NO_CHUNK;
+	c.fill = 0;
+	c.overflow = false;
+	const StageDesc *stages = uniptr(pipe->stages);
+	// small rounds spread over the CUs: consecutive ranks sit in different workgroups
+	const uint32_t rank = wave_in_block * n_wblocks + (b - 1);
+	const uint32_t epoch12 = x.epoch & 0xFFFu;
+	uint32_t my_round = 0; // (thread 0 only)
+	const uint32_t copy = b % POLR_RES_COPIES;
+	uint32_t it = 0;
+	while (true) {
+		if (threadIdx.x == 0) {
+			unsigned long long a, bw = 0;
+			const unsigned long long t0 = wall_clock64();
+			while (true) {
+				a = __hip_atomic_load(&x.sync->pub[copy].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((uint32_t)(a >> 52) == epoch12 && ((uint32_t)(a >> 32) & 0xFFFFFu) != my_round) {
+					break;
+				}
+				__builtin_amdgcn_s_sleep(8);
+				if (wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
+					a = POLR_RES_DONE; // lost: leave (the router reports the timeout)
+					break;
+				}
+			}
+			if ((uint32_t)a != POLR_RES_DONE) {
+				my_round = (uint32_t)(a >> 32) & 0xFFFFFu;
+				const uint32_t tag = polr_res_tag(x.epoch, my_round);
+				while (true) {
+					bw = __hip_atomic_load(&x.sync->pub[copy].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((uint32_t)(bw >> 50) == tag) {
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+					if (wall_clock64() - t0 > 2 * POLR_RES_TIMEOUT_TICKS) {
+						a = POLR_RES_DONE;
+						break;
+					}
+				}
+			}
+			bcast[it & 1][0] = a;
+			bcast[it & 1][1] = bw;
+			if (b == 1) {
+				RES_STAMP(x, it, 3)
+			}
+		}
+		__syncthreads();
+		const unsigned long long a = bcast[it & 1][0];
+		const unsigned long long bw = bcast[it & 1][1];
+		it++;
+		const uint32_t count = uni((uint32_t)a);
+		if (count == POLR_RES_DONE) {
+			break;
+		}
+		const uint64_t rb = uni((uint32_t)bw);
+		const uint32_t us = uni((uint32_t)(bw >> 32) & 0xFFFu);
+		const uint32_t pidx = uni((uint32_t)(bw >> 44) & 31u);
+		const bool emit = uni((uint32_t)(bw >> 49) & 1u) != 0;
+		const uint32_t n_units = (count + us - 1) / us;
+		if (rank < n_units) {
+			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)pidx * POLR_KMAX);
+			uint32_t *dst = (uint32_t *)c.desc;
+			for (uint32_t i = c.lane; i < K * STAGE_DESC_DWORDS; i += 64) {
+				dst[i] = src[i];
+			}
+			c.emit = emit && !c.overflow;
+			c.wide0 = uni(src[offsetof(StageDesc, unique) / 4]) != 0;
+			uint32_t my_units = 0;
+			for (uint32_t unit = rank; unit < n_units; unit += n_workers) {
+				c.in_pos = rb + (uint64_t)unit * us;
+				c.in_end = c.in_pos + us;
+				if (c.in_end > rb + count) {
+					c.in_end = rb + count;
+				}
+				run_until_idle(c, false);
+				my_units++;
+			}
+			run_until_idle(c, true);
+			flush_counts(c, x.counts, 0);
+			if (c.lane == 0) {
+				// flush_token carries the returned values of the counter atomics: the arrival is issued after
+				// they have been performed
+				atomicAdd(&x.sync->arrived[b % POLR_RES_ARRIVE].v, (unsigned long long)my_units + c.flush_token);
+				if (b == 1 && wave_in_block == 0) {
+					RES_STAMP(x, it - 1, 4)
+				}
+			}
+		}
+	}
+	if (c.cur_chunk != NO_CHUNK && c.lane == 0) {
+		out.chunk_count[c.cur_chunk] = c.fill;
+	}
+}
+#else
 template <int W, int K>
 __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__restrict__ pipe,
                                                         const DevRound *__restrict__ rounds,
@@ -844,6 +1000,8 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 	}
 }
 
+#endif // POLR_RESIDENT_KERNEL
+
 // ---- launch ------------------------------------------------------------------------------------
 #define PASTE2(a, b) a##b
 #define PASTE(a, b) PASTE2(a, b)
@@ -855,10 +1013,91 @@ static size_t lds_bytes_k(uint32_t W, uint32_t waves_per_block) {
 	       64; // + the static arrival flag of a self-routing launch
 }
 
+#ifndef POLR_RESIDENT_KERNEL
 extern "C++" size_t PASTE(polr_path_lds_bytes_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
 	return lds_bytes_k(W, waves_per_block);
 }
+#endif
 
+#ifdef POLR_RESIDENT_KERNEL
+static size_t lds_set_res[16] = {0};
+
+template <int W>
+static hipError_t prepare_res(size_t lds) {
+	if (lds > lds_set_res[W]) {
+		hipError_t e = hipFuncSetAttribute((const void *)polr_resident_kernel<W, POLR_K>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) {
+			return e;
+		}
+		lds_set_res[W] = lds;
+	}
+	return hipSuccess;
+}
+
+template <int W>
+static int occupancy_res(size_t lds, uint32_t threads) {
+	int blocks = 0;
+	if (prepare_res<W>(lds) != hipSuccess ||
+	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_resident_kernel<W, POLR_K>, (int)threads,
+	                                                 lds) != hipSuccess) {
+		return 0;
+	}
+	return blocks;
+}
+
+// cooperative launch: the runtime refuses a grid that cannot be co-resident, which is what the static
+// unit -> worker assignment of the resident kernel relies on
+template <int W>
+static hipError_t launch_res(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const DevPipeline *pipe,
+                             const ResidentExec *execs, uint32_t n_exec, DevOut out) {
+	hipError_t e = prepare_res<W>(lds);
+	if (e != hipSuccess) {
+		return e;
+	}
+	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&n_exec, (void *)&out};
+	return hipLaunchCooperativeKernel((const void *)polr_resident_kernel<W, POLR_K>, grid, block, args, (uint32_t)lds,
+	                                  stream);
+}
+
+template <int N>
+struct Wc {
+	static constexpr int v = (N <= POLR_K + 1) ? N : 1;
+};
+#define POLR_FOR_EACH_W(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+
+extern "C++" int PASTE(polr_resident_occupancy_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
+	const size_t lds = lds_bytes_k(W, waves_per_block);
+	if (W < 1 || W > POLR_K + 1) {
+		return 0;
+	}
+#define OCC_CASE(N)                                                                                                    \
+	if (W == N) {                                                                                                      \
+		return occupancy_res<Wc<N>::v>(lds, 64 * waves_per_block);                                                     \
+	}
+	POLR_FOR_EACH_W(OCC_CASE)
+#undef OCC_CASE
+	return 0;
+}
+
+extern "C++" hipError_t PASTE(polr_launch_resident_kernel_k, POLR_K)(uint32_t W, uint32_t n_blocks,
+                                                                     uint32_t waves_per_block, hipStream_t stream,
+                                                                     const DevPipeline *pipe, const ResidentExec *execs,
+                                                                     uint32_t n_exec, DevOut out) {
+	const size_t lds = lds_bytes_k(W, waves_per_block);
+	dim3 grid(n_blocks), block(64 * waves_per_block);
+	if (W < 1 || W > POLR_K + 1) {
+		return hipErrorInvalidValue;
+	}
+#define LAUNCH_CASE(N)                                                                                                 \
+	if (W == N) {                                                                                                      \
+		return launch_res<Wc<N>::v>(grid, block, lds, stream, pipe, execs, n_exec, out);                               \
+	}
+	POLR_FOR_EACH_W(LAUNCH_CASE)
+#undef LAUNCH_CASE
+	return hipErrorInvalidValue;
+}
+#else
 template <int W>
 static hipError_t launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const DevPipeline *pipe,
                            const DevRound *rounds, const uint64_t *unit_prefix, uint32_t n_rounds,
@@ -930,3 +1169,4 @@ extern "C++" hipError_t PASTE(polr_launch_path_kernel_k, POLR_K)(uint32_t W, uin
 #undef LAUNCH_CASE
 	return hipErrorInvalidValue;
 }
+#endif // POLR_RESIDENT_KERNEL

@@ -29,7 +29,7 @@ EXPORTS = [
     "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
-    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many",
+    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
     L.polr_mpx_reset.argtypes = [vp, vp]
     L.polr_mpx_run_many.argtypes = [vp, vp, vp, vp, u32, vp]
     L.polr_mpx_finish_many.argtypes = [vp, u32, vp]
+    L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
     _lib = L
@@ -402,6 +403,10 @@ class DeviceMultiplexer:
     def run(self, chunk_begin, chunk_end, out=None, stream=None):
         self.ctx.check(self.ctx.L.polr_mpx_run(self.h, stream, chunk_begin, chunk_end, out.h if out else None))
 
+    def run_resident(self, chunk_begin, chunk_end, out=None):
+        """the same run as one cooperative launch (polr_mpx_run_resident with this single executor)"""
+        run_resident([self], [(chunk_begin, chunk_end)], out)
+
     def finish(self, stream=None):
         st = MpxStats()
         self.ctx.check(self.ctx.L.polr_mpx_finish(self.h, stream, C.byref(st)))
@@ -462,6 +467,21 @@ def _stats_dict(st, P, k):
             "input_tuple_count_per_path": [st.input_tuple_count_per_path[i] for i in range(P)],
             "path_resistances": [st.path_resistances[i] for i in range(P)],
             "stage_out": [[st.stage_out[i][j] for j in range(k)] for i in range(P)]}
+
+
+RUN_RESET, RUN_FINISH = 1, 2
+
+
+def run_resident(mpxs, ranges, out=None, reset=False, finish=False):
+    """polr_mpx_run_resident: the same run as ONE cooperative launch (device-resident routing loop);
+    reset / finish fold polr_mpx_reset / the closing FinalizePathRun into the same launch"""
+    ctx = mpxs[0].ctx
+    n = len(mpxs)
+    hs = (C.c_void_p * n)(*[m.h for m in mpxs])
+    b = np.ascontiguousarray([r[0] for r in ranges], dtype=np.uint64)
+    e = np.ascontiguousarray([r[1] for r in ranges], dtype=np.uint64)
+    ctx.check(ctx.L.polr_mpx_run_resident(hs, None, b.ctypes.data, e.ctypes.data, n, out.h if out else None,
+                                          (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0)))
 
 
 def finish_many(mpxs):

@@ -244,6 +244,20 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
  * device.  All multiplexers must belong to the same pipeline; `out` (may be NULL) is shared. */
 int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                       uint32_t n, polr_out *out);
+/* The same run as ONE cooperative kernel launch ("resident"): the grid is split between the n executors
+ * (workgroup % n; with n = 8 one executor per XCD), every executor has a router workgroup that keeps its
+ * multiplexer state in LDS and probe workgroups that wait for its rounds on the device -- no launch and no
+ * host step between two routing decisions.  Same routing, same results as polr_mpx_run / _run_many with the
+ * same chunk ranges.  All executors run on `stream` (NULL: the first multiplexer's).  Asynchronous;
+ * polr_mpx_finish(_many) synchronises and reports POLR_E_HIP if the device-side watchdog fired.
+ * flags: POLR_RUN_RESET = start from a fresh MultiplexerState (what polr_mpx_reset does, without a launch
+ * of its own); POLR_RUN_FINISH = close the run inside the same launch (PushFinalize's FinalizePathRun) and
+ * leave the statistics where polr_mpx_finish(_many) picks them up without launching anything.
+ * POLR_E_UNSUPPORTED: more than 64 executors / more executors than fit on the device at once. */
+#define POLR_RUN_RESET 1u
+#define POLR_RUN_FINISH 2u
+int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
+                          uint32_t n, polr_out *out, uint32_t flags);
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
 /* fresh MultiplexerState (a new PipelineExecutor / a new pass over the source) */
 int polr_mpx_reset(polr_mpx *m, void *stream);

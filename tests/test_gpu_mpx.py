@@ -37,8 +37,20 @@ def pipeline_for(ctx, name, enumerator):
     return _pipes[key]
 
 
+def _run(mpx, launch, a, b, out=None):
+    """per-round self-routing launches, or the whole run as one resident (cooperative) launch"""
+    if launch == "resident":
+        mpx.run_resident(a, b, out=out)
+    else:
+        mpx.run(a, b, out=out)
+
+
+LAUNCHES = ["rounds", "resident"]
+
+
+@pytest.mark.parametrize("launch", LAUNCHES)
 @pytest.mark.parametrize("name,key", _cases())
-def test_device_routing_matches_reference(gpu_ctx, name, key):
+def test_device_routing_matches_reference(gpu_ctx, name, key, launch):
     gold = common.load_golden(name)
     g = gold["routing"][key]
     parts = key.split("/")
@@ -59,7 +71,7 @@ def test_device_routing_matches_reference(gpu_ctx, name, key):
     # route the source in three morsels: state (incl. an open routing window) carries across calls
     cuts = [0, n_chunks // 3, n_chunks // 3 + 1, n_chunks]
     for a, b in zip(cuts[:-1], cuts[1:]):
-        mpx.run(a, b, out=out)
+        _run(mpx, launch, a, b, out=out)
     st = mpx.finish()
     path, tuples, inter = mpx.fetch_log()
     assert list(inter) == g["rounds"]
@@ -76,14 +88,15 @@ def test_device_routing_matches_reference(gpu_ctx, name, key):
         assert common.rows_digest_from_columns(cols) == (g["rows_sha256"], g["n_rows"])
 
 
+@pytest.mark.parametrize("launch", LAUNCHES)
 @pytest.mark.parametrize("name", list(SCENARIOS))
-def test_device_alternate_matches_reference(gpu_ctx, name):
+def test_device_alternate_matches_reference(gpu_ctx, name, launch):
     gold = common.load_golden(name)
     g = gold["alternate"]["each_last_once"]
     wl, paths, pipe, joins, n = pipeline_for(gpu_ctx, name, "each_last_once")
     mpx = capi.DeviceMultiplexer(pipe, "alternate", chunk_size=1024)
     out = capi.Output(pipe, 1024, 8192)
-    mpx.run(0, (n + 1023) // 1024, out=out)
+    _run(mpx, launch, 0, (n + 1023) // 1024, out=out)
     st = mpx.finish()
     path, tuples, inter = mpx.fetch_log()
     P = len(paths)
@@ -93,9 +106,10 @@ def test_device_alternate_matches_reference(gpu_ctx, name):
     assert not overflow and n_rows == g["n_rows"]  # only path 0 forwards its output
 
 
+@pytest.mark.parametrize("launch", LAUNCHES)
 @pytest.mark.parametrize("routing", ["init_once", "opportunistic", "adaptive_reinit", "dynamic",
                                      "exponential_backoff", "default_path"])
-def test_bench_workload_matches_reference(gpu_ctx, routing):
+def test_bench_workload_matches_reference(gpu_ctx, routing, launch):
     """bench.py's pipeline (selection list + thinned chunk offsets + COUNT(*) sink) at scale 0.1 against the
     reference's own run of the same SQL"""
     from test_oracle_golden import _job_light, job_light_budget
@@ -106,7 +120,7 @@ def test_bench_workload_matches_reference(gpu_ctx, routing):
     pipe.set_selection(sel)
     mpx = capi.DeviceMultiplexer(pipe, routing, regret_budget=job_light_budget(routing, n_rows))
     mpx.set_chunk_offsets(offs)
-    mpx.run(0, len(offs) - 1)
+    _run(mpx, launch, 0, len(offs) - 1)
     st = mpx.finish()
     path, tuples, inter = mpx.fetch_log()
     g = gold["routing"][routing]
@@ -116,3 +130,53 @@ def test_bench_workload_matches_reference(gpu_ctx, routing):
     # COUNT(*): the last join's output over all paths
     k = 2
     assert sum(st["stage_out"][p][k - 1] for p in range(2)) == gold["count_star"]
+
+
+def _sorted_rows(ids):
+    return ids[np.lexsort(ids.T[::-1])]
+
+
+@pytest.mark.parametrize("launch", ["many", "resident"])
+@pytest.mark.parametrize("n_exec", [2, 3, 8])
+def test_executors_match_single_executor_runs(gpu_ctx, launch, n_exec):
+    """E executors over disjoint chunk ranges (polr_mpx_run_many / _run_resident) = E independent
+    single-executor runs over the same ranges: same round logs, same statistics, same output row set"""
+    wl, paths, pipe, joins, n = pipeline_for(gpu_ctx, "star_skew", "each_last_once")
+    n_chunks = (n + 1023) // 1024
+    ranges = [((e * n_chunks) // n_exec, ((e + 1) * n_chunks) // n_exec) for e in range(n_exec)]
+    want_logs, want_stats = [], []
+    ref_out = capi.Output(pipe, 1024, 8192)
+    for a, b in ranges:
+        m = capi.DeviceMultiplexer(pipe, "adaptive_reinit", chunk_size=1024)
+        m.run(a, b, out=ref_out)
+        want_stats.append(m.finish())
+        want_logs.append(m.fetch_log())
+        m.close()
+    want_rows = _sorted_rows(ref_out.fetch_ids())
+    mpxs = [capi.DeviceMultiplexer(pipe, "adaptive_reinit", chunk_size=1024) for _ in range(n_exec)]
+    out = capi.Output(pipe, 1024, 8192)
+    for rep in range(2):  # a second pass after reset: sync words and epochs carry over correctly
+        out.reset()
+        gpu_ctx.sync()  # (the output object is reset on the context's stream, the runs use their own)
+        if launch == "many" or rep == 0:
+            for m in mpxs:
+                m.reset()
+        if launch == "many":
+            capi.run_many(mpxs, ranges, out=out)
+        elif rep == 0:
+            capi.run_resident(mpxs, ranges, out=out)
+        else:  # reset and closing FinalizePathRun folded into the same launch
+            capi.run_resident(mpxs, ranges, out=out, reset=True, finish=True)
+        stats = capi.finish_many(mpxs)
+        for e in range(n_exec):
+            for key in ("num_intermediates", "num_rounds", "input_tuple_count_per_path", "path_resistances",
+                        "stage_out"):
+                assert stats[e][key] == want_stats[e][key], (rep, e, key)
+            got = mpxs[e].fetch_log()
+            for a_, b_ in zip(got, want_logs[e]):
+                assert np.array_equal(a_, b_)
+        n_rows, _, overflow = out.stats()
+        assert not overflow
+        assert np.array_equal(_sorted_rows(out.fetch_ids()), want_rows)
+    for m in mpxs:
+        m.close()
