@@ -702,7 +702,7 @@ __device__ __forceinline__ void flush_counts(WaveCtx<W, K> &c, unsigned long lon
 // an executor routes, the others probe.  Worker waves keep their pipeline state (queues, partially filled
 // output chunk) across rounds; between rounds a workgroup sleeps on its barrier while its first thread polls.
 template <int W, int K>
-__global__ __launch_bounds__(256) void polr_resident_kernel(const DevPipeline *__restrict__ pipe,
+__global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline *__restrict__ pipe,
                                                             const ResidentExec *__restrict__ execs, uint32_t n_exec,
                                                             DevOut out) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];

@@ -22,7 +22,7 @@ for e in range(E):
 ranges = [((e * nc) // E, ((e + 1) * nc) // E) for e in range(E)]
 for it in range(3):
     for m in mpxs: m.reset()
-    capi.run_resident(mpxs, ranges)
+    capi.run_resident(mpxs, ranges, reset=True, finish=True)
     capi.finish_many(mpxs)
 L = ctx.L
 L.polr_mpx_dump_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
