@@ -156,13 +156,14 @@ def main():
     ap.add_argument("--init-tuple-count", type=int, default=1024)
     ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
     ap.add_argument("--max-join-orders", type=int, default=8, help="SET max_join_orders (bank size cap)")
-    ap.add_argument("--executors", type=int, default=1,
+    ap.add_argument("--executors", type=int, default=8,
                     help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
-                         "contiguous share of the source chunks on its own HIP stream -- the counterpart of the "
-                         "reference's worker threads (one PipelineExecutor + MultiplexerState per thread, "
-                         "pipeline.cpp:145-174); 1 = the single-executor trace the parity tests pin")
+                         "contiguous share of the source chunks -- the counterpart of the reference's worker "
+                         "threads (one PipelineExecutor + MultiplexerState per thread, pipeline.cpp:145-174). "
+                         "Default 8 = one executor per XCD of the MI355X; 1 = the single-executor trace the parity "
+                         "tests pin against the single-threaded reference")
     ap.add_argument("--launch", default="resident", choices=["resident", "rounds"],
-                    help="resident: the whole pass is ONE cooperative launch (device-resident routing loop, "
+                    help="resident: the whole pass is ONE launch (device-resident routing loop, "
                          "polr_mpx_run_resident); rounds: one self-routing launch per routing round "
                          "(polr_mpx_run / _run_many)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -337,17 +338,27 @@ def main():
             tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get("hbm_bytes_per_step")
+                    tj = json.load(open(tp))
+                    # measured PMC traffic of the SAME kernel and configuration only (else: not measured)
+                    same = tj.get("kernel") == ("polr_resident_kernel" if args.launch == "resident" else
+                                                "polr_path_kernel") and \
+                        tj.get("config", {}).get("executors_per_gpu") == E and \
+                        tj.get("config", {}).get("routing") == args.routing and args.scale == 1.0
+                    traffic = tj.get("hbm_bytes_per_launch") if same else None
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "polr_path_kernel", "algorithmic_bytes_per_step": round(alg),
+                    "kernel": "polr_resident_kernel" if args.launch == "resident" else "polr_path_kernel",
+                    "algorithmic_bytes_per_step": round(alg),
                     "kernel_ms_per_step": round(kernel_ms / args.steps, 4),
                     "launches_per_step": launches / args.steps,
                     "ms_per_step_with_events": round(dt_events / args.steps * 1e3, 4),
-                    "note": "one launch = one routed path run (probe + route next); algorithmic bytes and kernel "
-                            "time are summed over all launches of a step"}
+                    "note": ("one launch = the whole pass: every executor's routing loop and all its probe rounds "
+                             "(the kernel time includes the device-side waits between dependent routing rounds)"
+                             if args.launch == "resident" else
+                             "one launch = one routed path run (probe + route next); algorithmic bytes and kernel "
+                             "time are summed over all launches of a step")}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -376,6 +387,14 @@ def main():
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(line))
+    # release the device objects while the runtime (and a profiler attached to it) is still alive: nothing is
+    # left for interpreter shutdown to destroy in an arbitrary order
+    for m in mpxs:
+        m.close()
+    pipe.close()
+    for ht, _ in joins:
+        ht.close()
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

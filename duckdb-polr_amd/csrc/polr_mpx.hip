@@ -435,7 +435,7 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
 	return rc;
 }
 
-// The whole run in ONE cooperative launch: every executor gets a slice of the grid (its router workgroup +
+// The whole run in ONE launch: every executor gets a slice of the grid (its router workgroup +
 // probe workgroups), routing decisions never leave the device, the host only enqueues.  Asynchronous:
 // polr_mpx_finish / _finish_many synchronise.
 int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,

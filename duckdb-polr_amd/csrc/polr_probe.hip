@@ -1046,8 +1046,10 @@ static int occupancy_res(size_t lds, uint32_t threads) {
 	return blocks;
 }
 
-// cooperative launch: the runtime refuses a grid that cannot be co-resident, which is what the static
-// unit -> worker assignment of the resident kernel relies on
+// The grid is sized by the caller from the occupancy of THIS kernel (never more workgroups than are
+// co-resident on an idle device), which is what the static unit -> worker assignment relies on; a device
+// shared with other work is covered by the watchdog in the wait loops.  A plain launch: the runtime's
+// cooperative launch goes through a separate device-wide queue and costs ~20 us of cross-queue barriers.
 template <int W>
 static hipError_t launch_res(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const DevPipeline *pipe,
                              const ResidentExec *execs, uint32_t n_exec, DevOut out) {
@@ -1055,9 +1057,8 @@ static hipError_t launch_res(dim3 grid, dim3 block, size_t lds, hipStream_t stre
 	if (e != hipSuccess) {
 		return e;
 	}
-	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&n_exec, (void *)&out};
-	return hipLaunchCooperativeKernel((const void *)polr_resident_kernel<W, POLR_K>, grid, block, args, (uint32_t)lds,
-	                                  stream);
+	hipLaunchKernelGGL((polr_resident_kernel<W, POLR_K>), grid, block, lds, stream, pipe, execs, n_exec, out);
+	return hipGetLastError();
 }
 
 template <int N>

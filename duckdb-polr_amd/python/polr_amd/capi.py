@@ -404,7 +404,7 @@ class DeviceMultiplexer:
         self.ctx.check(self.ctx.L.polr_mpx_run(self.h, stream, chunk_begin, chunk_end, out.h if out else None))
 
     def run_resident(self, chunk_begin, chunk_end, out=None):
-        """the same run as one cooperative launch (polr_mpx_run_resident with this single executor)"""
+        """the same run as one launch (polr_mpx_run_resident with this single executor)"""
         run_resident([self], [(chunk_begin, chunk_end)], out)
 
     def finish(self, stream=None):
@@ -473,7 +473,7 @@ RUN_RESET, RUN_FINISH = 1, 2
 
 
 def run_resident(mpxs, ranges, out=None, reset=False, finish=False):
-    """polr_mpx_run_resident: the same run as ONE cooperative launch (device-resident routing loop);
+    """polr_mpx_run_resident: the same run as ONE launch (device-resident routing loop);
     reset / finish fold polr_mpx_reset / the closing FinalizePathRun into the same launch"""
     ctx = mpxs[0].ctx
     n = len(mpxs)

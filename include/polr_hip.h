@@ -244,7 +244,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
  * device.  All multiplexers must belong to the same pipeline; `out` (may be NULL) is shared. */
 int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                       uint32_t n, polr_out *out);
-/* The same run as ONE cooperative kernel launch ("resident"): the grid is split between the n executors
+/* The same run as ONE kernel launch ("resident"): the grid is split between the n executors
  * (workgroup % n; with n = 8 one executor per XCD), every executor has a router workgroup that keeps its
  * multiplexer state in LDS and probe workgroups that wait for its rounds on the device -- no launch and no
  * host step between two routing decisions.  Same routing, same results as polr_mpx_run / _run_many with the

@@ -38,7 +38,7 @@ def pipeline_for(ctx, name, enumerator):
 
 
 def _run(mpx, launch, a, b, out=None):
-    """per-round self-routing launches, or the whole run as one resident (cooperative) launch"""
+    """per-round self-routing launches, or the whole run as one resident launch"""
     if launch == "resident":
         mpx.run_resident(a, b, out=out)
     else:
