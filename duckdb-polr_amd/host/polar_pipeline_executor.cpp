@@ -42,7 +42,7 @@ bool POLARPipelineExecutor::Execute(RoutingPlacement placement, polr_out *out) {
 	if (placement == RoutingPlacement::HOST_ROUTED) {
 		ExecuteHostRouted(out);
 	} else {
-		ExecuteDeviceRouted(out);
+		ExecuteDeviceRouted(out, placement == RoutingPlacement::DEVICE_RESIDENT);
 	}
 	return true;
 }
@@ -147,7 +147,7 @@ void POLARPipelineExecutor::ExecuteHostRouted(polr_out *out) {
 	context.config.log_tuples_routed = log_was;
 }
 
-void POLARPipelineExecutor::ExecuteDeviceRouted(polr_out *out) {
+void POLARPipelineExecutor::ExecuteDeviceRouted(polr_out *out, bool resident) {
 	auto &multiplexer = *polar.multiplexer;
 	polr_mpx_config cfg;
 	memset(&cfg, 0, sizeof(cfg));
@@ -164,7 +164,13 @@ void POLARPipelineExecutor::ExecuteDeviceRouted(polr_out *out) {
 		if (!chunk_offsets.empty()) {
 			Check(ctx, polr_mpx_set_chunk_offsets(mpx, chunk_offsets.data(), n_chunks), "polr_mpx_set_chunk_offsets");
 		}
-		Check(ctx, polr_mpx_run(mpx, nullptr, 0, n_chunks, out), "polr_mpx_run");
+		if (resident) {
+			const uint64_t begin = 0, end = n_chunks;
+			Check(ctx, polr_mpx_run_resident(&mpx, nullptr, &begin, &end, 1, out, POLR_RUN_FINISH),
+			      "polr_mpx_run_resident");
+		} else {
+			Check(ctx, polr_mpx_run(mpx, nullptr, 0, n_chunks, out), "polr_mpx_run");
+		}
 		polr_mpx_stats stats;
 		Check(ctx, polr_mpx_finish(mpx, nullptr, &stats), "polr_mpx_finish");
 		num_intermediates_produced = stats.num_intermediates;

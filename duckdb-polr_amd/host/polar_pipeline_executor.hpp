@@ -10,7 +10,10 @@
 //   HOST_ROUTED    PhysicalMultiplexer::Execute on the host per routing decision, polr_probe_rounds per
 //                  run, AddNumIntermediates with the counters that come back.  One device round trip per
 //                  decision: the literal transcription of RunPath, used to check the device router.
-//   DEVICE_ROUTED  the multiplexer state lives in HBM (polr_mpx_*): no host round trip per decision.
+//   DEVICE_ROUTED  the multiplexer state lives in HBM (polr_mpx_run): the path kernel routes for itself,
+//                  one launch per routing round, no host round trip per decision.
+//   DEVICE_RESIDENT the whole run is one launch (polr_mpx_run_resident): router wave + probe workgroups
+//                  stay on the device until the source is exhausted.
 //
 // Chunk caches and the in_process_joins stack of the reference only regroup tuples into fuller chunks;
 // they change neither the intermediates of a run nor the output row set, so they have no counterpart
@@ -21,7 +24,7 @@
 
 namespace duckdb_polr {
 
-enum class RoutingPlacement : uint8_t { HOST_ROUTED, DEVICE_ROUTED };
+enum class RoutingPlacement : uint8_t { HOST_ROUTED, DEVICE_ROUTED, DEVICE_RESIDENT };
 
 class POLARPipelineExecutor {
 public:
@@ -45,7 +48,7 @@ public:
 
 private:
 	void ExecuteHostRouted(polr_out *out);
-	void ExecuteDeviceRouted(polr_out *out);
+	void ExecuteDeviceRouted(polr_out *out, bool resident);
 	idx_t ChunkStart(idx_t c) const;
 
 	ClientContext &context;

@@ -240,7 +240,9 @@ int polr_host_run_pipeline(polr_ctx *ctx, polr_pipeline *pipe, int k, int n_path
 			offs.assign(chunk_offsets, chunk_offsets + n_chunks + 1);
 		}
 		POLARPipelineExecutor exec(client, polar, ctx, pipe, n_tuples, offs);
-		exec.Execute(placement ? RoutingPlacement::DEVICE_ROUTED : RoutingPlacement::HOST_ROUTED, out);
+		exec.Execute(placement == 2 ? RoutingPlacement::DEVICE_RESIDENT
+		                            : (placement ? RoutingPlacement::DEVICE_ROUTED : RoutingPlacement::HOST_ROUTED),
+		             out);
 		memset(res, 0, sizeof(*res));
 		res->num_intermediates = exec.num_intermediates_produced;
 		res->n_rounds = exec.intermediates_per_round.size();

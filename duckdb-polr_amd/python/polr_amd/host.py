@@ -143,7 +143,8 @@ def generate_join_orders(enumerator, n_probe_cols, n_build_cols, cond_left_index
 
 def run_pipeline(pipe, paths, routing, n_tuples, regret_budget=0.01, init_tuple_count=1024, atc_multiplier=1,
                  chunk_offsets=None, device_routed=False, out=None, max_rounds=1 << 20):
-    """POLARPipelineExecutor::Execute over a device pipeline (capi.Pipeline)"""
+    """POLARPipelineExecutor::Execute over a device pipeline (capi.Pipeline); device_routed: False = host-routed,
+    True = self-routing launches (DEVICE_ROUTED), 2 = one resident launch (DEVICE_RESIDENT)"""
     L = load()
     paths = np.ascontiguousarray(np.asarray(paths, dtype=np.int32).reshape(-1, pipe.k))
     res = RunResult()

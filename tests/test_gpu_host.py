@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", list(SCENARIOS))
 @pytest.mark.parametrize("routing", ["adaptive_reinit", "init_once", "opportunistic", "dynamic",
                                      "exponential_backoff", "default_path"])
-@pytest.mark.parametrize("device_routed", [False, True])
+@pytest.mark.parametrize("device_routed", [False, True, 2])  # host-routed, self-routing launches, resident
 def test_executor_matches_reference(gpu_ctx, name, routing, device_routed):
     gold = common.load_golden(name)
     g = gold["routing"]["each_last_once/%s/nocache" % routing]
@@ -36,10 +36,12 @@ def test_host_and_device_routing_agree_bitwise(gpu_ctx):
     wl, paths, pipe, joins, n = pipeline_for(gpu_ctx, "star_skew", "each_last_once")
     for routing in ("adaptive_reinit", "dynamic", "exponential_backoff"):
         a = host.run_pipeline(pipe, paths, routing, n, device_routed=False)
-        b = host.run_pipeline(pipe, paths, routing, n, device_routed=True)
-        assert np.array_equal(a["rounds"], b["rounds"])
-        assert np.array_equal(a["round_path"], b["round_path"]) and np.array_equal(a["round_tuples"], b["round_tuples"])
-        assert a["path_resistances"] == b["path_resistances"]
+        for placement in (True, 2):  # self-routing launches, resident launch
+            b = host.run_pipeline(pipe, paths, routing, n, device_routed=placement)
+            assert np.array_equal(a["rounds"], b["rounds"])
+            assert np.array_equal(a["round_path"], b["round_path"])
+            assert np.array_equal(a["round_tuples"], b["round_tuples"])
+            assert a["path_resistances"] == b["path_resistances"]
 
 
 @pytest.mark.parametrize("perfect", [False, True])
