@@ -908,7 +908,8 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 			d.range = dj.range;
 			d.sentinel_start = dj.sentinel_start;
 			d.sentinel_count = dj.sentinel_count;
-			d.unique = (ht->kind == KIND_PERFECT || ht->kind == KIND_S8 || ht->max_run <= 1) ? 1u : 0u;
+			// 1: at most one match per tuple; 2: keys may repeat (wide steps fall back to a narrow one where they do)
+			d.unique = (ht->kind == KIND_PERFECT || ht->kind == KIND_S8 || ht->max_run <= 1) ? 1u : 2u;
 		}
 	}
 }

@@ -77,7 +77,7 @@ struct StageDesc {
 	uint64_t range;
 	uint32_t sentinel_start;
 	uint32_t sentinel_count;
-	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1)
+	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1); 2: keys may repeat
 	uint32_t pad;
 };
 #define STAGE_DESC_DWORDS (sizeof(StageDesc) / 4)

@@ -222,12 +222,8 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer allocation failed: %s", hipGetErrorString(e));
 	}
 	m->cfg.max_log_rounds = (uint32_t)max_log;
-	for (uint32_t q = 0; q < p->n_paths; q++) {
-		const polr_ht *ht0 = p->hts[p->host_count.paths[q].order[0]];
-		if (ht0->kind == KIND_PERFECT || ht0->kind == KIND_S8 || ht0->max_run <= 1) {
-			m->wide0_mask |= 1u << q;
-		}
-	}
+	// every stage 0 takes wide (256-tuple) steps, so units are multiples of 256 tuples
+	m->wide0_mask = p->n_paths >= 32 ? 0xFFFFFFFFu : ((1u << p->n_paths) - 1u);
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, ctx->stream, m->dev, m->cfg, p->n_paths, p->n_tuples,
 	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask, m->progress_dev, 0u);
 	e = hipStreamSynchronize(ctx->stream);

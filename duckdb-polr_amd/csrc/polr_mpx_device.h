@@ -234,10 +234,12 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 	round->path = (uint32_t)path;
 	// ALTERNATE forwards only path 0's output (polar_pipeline_executor.cpp:445-447,514-523)
 	round->emit = (core.routing != polr::ALTERNATE || path == 0) ? 1u : 0u;
-	// unit size: one unit = what one wave takes per visit.  A wide stage-0 step eats 256 tuples, and
-	// every busy workgroup costs an arrival atomic at the end of the launch, so never go below 256; a
-	// table-sized round gives every resident wave a few units.
-	const uint64_t gran = ((m->wide0_mask >> path) & 1u) ? 256 : 64; // tuples one stage-0 step takes
+	// unit size: one unit = what one wave takes per visit; a table-sized round gives every resident wave a
+	// few units.  Per-round launches: every busy workgroup costs an arrival atomic at the end of the launch, and a wide
+	// stage-0 step eats 256 tuples, so units are multiples of 256.  Resident run (the caller passes its
+	// chunk-offset cache): waves are there anyway, a small round is spread 64 tuples per wave -- the dependent-load chain of
+	// a step is the same for 64 and for 256 tuples, so more waves in parallel is strictly faster.
+	const uint64_t gran = (oc == nullptr && ((m->wide0_mask >> path) & 1u)) ? 256 : 64;
 	uint64_t us = (tuples + resident_waves - 1) / resident_waves;
 	us = ((us + gran - 1) / gran) * gran;
 	us = us < gran ? gran : (us > 2048 ? 2048 : us);
@@ -389,6 +391,13 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		}
 	}
 	DevMpx *m = (DevMpx *)lds;
+	// nobody on the host follows the steps of a resident run: keep the (PCIe) progress stores off the routing
+	// path; the pointer is restored before the state goes back to HBM
+	volatile uint32_t *const host_words = mg->progress;
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		m->progress = nullptr;
+	}
 	DevRound *round = (DevRound *)(lds + POLR_RES_HOT_DWORDS); // 24 bytes
 	uint64_t *prefix = (uint64_t *)(lds + POLR_RES_HOT_DWORDS + 8);
 	uint32_t *us = lds + POLR_RES_HOT_DWORDS + 12;
@@ -431,9 +440,6 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		if (lane == 0) {
 			RES_STAMP(x, n_steps, 0)
 		}
-		if (x.chunk_offsets && n_steps == 0) {
-			polr_offs_cache_fill(oc, x, x.chunk_begin, cache_cap, lane);
-		}
 		// (a reset run drops whatever the counters still hold: first step only)
 		polr_router_step_impl(m, mg, round, prefix, us, x.counts, k, n_workers, lane, true, &oc, reset && n_steps == 0);
 		__builtin_amdgcn_wave_barrier();
@@ -461,7 +467,7 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		// while the workers probe: keep the boundaries of the chunks ahead in LDS
 		{
 			const uint64_t ci = ((volatile DevMpx *)m)->chunk_idx;
-			if (x.chunk_offsets && ci - oc.base >= oc.n / 2) {
+			if (x.chunk_offsets && ci - oc.base >= oc.n / 2) { // (also the first fill: n == 0)
 				polr_offs_cache_fill(oc, x, ci, cache_cap, lane);
 			}
 		}
@@ -483,8 +489,8 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 			__hip_atomic_store(&x.sync->pub[lane].a,
 			                   polr_res_word_a(x.epoch, polr_res_next_round(round_no), POLR_RES_DONE), __ATOMIC_RELAXED,
 			                   __HIP_MEMORY_SCOPE_AGENT);
-			if (lane == 0 && m->progress) {
-				m->progress[2] = 1;
+			if (lane == 0 && host_words) {
+				host_words[2] = 1;
 			}
 			break;
 		}
@@ -496,6 +502,14 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		}
 		__builtin_amdgcn_wave_barrier();
 		polr_write_stats(m, mg, x.stats_out, lane);
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		m->progress = host_words;
+		if (host_words) { // what a per-round run would have published: the run is over
+			host_words[1] = m->done;
+			host_words[0] = m->steps_done;
+		}
 	}
 	__builtin_amdgcn_wave_barrier();
 	{

@@ -52,6 +52,12 @@ template <int W, int K>
 __device__ __host__ constexpr int qtotal() {
 	return K <= 1 ? 0 : W * QCAP1 + (K - 2) * W * QCAPN;
 }
+// dwords of LDS one wave owns: descriptors, queues, narrow pending areas [K][64] x 2, pinned stage-0 rows
+// [256], wide pending areas [2][256] x 2
+template <int W, int K>
+__device__ __host__ constexpr int per_wave_dwords() {
+	return K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64 * WIDE + 2 * 64 * WIDE * 2;
+}
 #define NO_CHUNK 0xFFFFFFFFu
 
 // diagnostic build only (-DPOLR_DIAG_STAMPS): wall-clock stamps of workgroup 0 / wave 0 at the phase
@@ -249,49 +255,66 @@ __device__ __forceinline__ bool lookup_s8(const Stage &s, uint64_t key, bool val
 	return p.hit;
 }
 
+struct S16Probe { // one in-flight {key64,start,count} probe
+	uint64_t group;
+	uint64_t key;
+	uint32_t first;
+	bool searching;
+	uint32_t start, count;
+};
+
+__device__ __forceinline__ void s16_begin(const Stage &s, uint64_t key, bool valid, S16Probe &p) {
+	p.key = key;
+	p.start = 0;
+	p.count = 0;
+	p.searching = valid;
+	if (valid && key == S16_EMPTY_KEY) {
+		p.start = s.sentinel_start;
+		p.count = s.sentinel_count;
+		p.searching = false;
+	}
+	const uint64_t h = polr_murmurhash64(key) & s.mask;
+	p.group = h >> 1; // 2 slots per group
+	p.first = (uint32_t)(h & 1);
+}
+
+__device__ __forceinline__ void s16_check(const Stage &s, S16Probe &p, const uint4 e0, const uint4 e1) {
+	if (p.first == 0) {
+		const uint64_t k0 = ((uint64_t)e0.y << 32) | e0.x;
+		if (k0 == S16_EMPTY_KEY) {
+			p.searching = false;
+		} else if (k0 == p.key) {
+			p.start = e0.z;
+			p.count = e0.w;
+			p.searching = false;
+		}
+	}
+	if (p.searching) {
+		const uint64_t k1 = ((uint64_t)e1.y << 32) | e1.x;
+		if (k1 == S16_EMPTY_KEY) {
+			p.searching = false;
+		} else if (k1 == p.key) {
+			p.start = e1.z;
+			p.count = e1.w;
+			p.searching = false;
+		}
+	}
+	p.first = 0;
+	p.group = (p.group + 1) & (s.mask >> 1);
+}
+
 __device__ __forceinline__ void lookup_s16(const Stage &s, uint64_t key, bool valid, uint32_t &start,
                                            uint32_t &count) {
 	const uint4 *tab = (const uint4 *)s.table;
-	start = 0;
-	count = 0;
-	if (!valid) {
-		return;
+	S16Probe p;
+	s16_begin(s, key, valid, p);
+	while (p.searching) {
+		const uint4 e0 = tab[p.group * 2];
+		const uint4 e1 = tab[p.group * 2 + 1];
+		s16_check(s, p, e0, e1);
 	}
-	if (key == S16_EMPTY_KEY) {
-		start = s.sentinel_start;
-		count = s.sentinel_count;
-		return;
-	}
-	const uint64_t h = polr_murmurhash64(key) & s.mask;
-	uint64_t group = h >> 1; // 2 slots per group
-	uint32_t first = (uint32_t)(h & 1);
-	const uint64_t gmask = s.mask >> 1;
-	while (true) {
-		const uint4 e0 = tab[group * 2];
-		const uint4 e1 = tab[group * 2 + 1];
-		if (first == 0) {
-			const uint64_t k0 = ((uint64_t)e0.y << 32) | e0.x;
-			if (k0 == S16_EMPTY_KEY) {
-				return;
-			}
-			if (k0 == key) {
-				start = e0.z;
-				count = e0.w;
-				return;
-			}
-		}
-		const uint64_t k1 = ((uint64_t)e1.y << 32) | e1.x;
-		if (k1 == S16_EMPTY_KEY) {
-			return;
-		}
-		if (k1 == key) {
-			start = e1.z;
-			count = e1.w;
-			return;
-		}
-		first = 0;
-		group = (group + 1) & gmask;
-	}
+	start = p.start;
+	count = p.count;
 }
 
 // ---- per-wave state ----------------------------------------------------------------------------
@@ -304,13 +327,16 @@ struct WaveCtx {
 	uint32_t *q;          // (K-1) queues, slot-major: q[qoff<W,pos>() + slot*qcap<pos>() + idx]
 	uint32_t *pend_start; // [K][64]
 	uint32_t *pend_pref;  // [K][64] inclusive prefix of run lengths
-	uint32_t *batch0;     // [64] probe rows of the pinned stage-0 batch
+	uint32_t *batch0;     // [256] probe rows of the pinned stage-0 step (a narrow batch uses the first 64)
 	// wave-uniform scalars, statically indexed
 	uint32_t qsize[K], pend_T[K], pend_cur[K], pend_base[K], cnt[K];
 	const uint32_t *sel;
 	uint64_t in_pos, in_end;
 	uint32_t flush_token; // depends on the returned values of the counter atomics (ordering only)
-	bool wide0; // stage 0 of the current join order yields <= 1 match per tuple: take 256 tuples per step
+	// bit p: stage p of the current join order takes wide steps (256 tuples, 4 lookups in flight per lane);
+	// pend_wide bit p: its pending expansion is a pinned wide step (wide pending area)
+	uint32_t wide_mask, pend_wide;
+	uint32_t *wpend_start, *wpend_pref; // [2][256]: slot 0 = stage 0, slot 1 = the last stage
 	// output
 	DevOut out;
 	bool emit;
@@ -527,39 +553,69 @@ __device__ __forceinline__ void run_stage(WaveCtx<W, K> &c) {
 	}
 }
 
-// Wide stage-0 step: 4 tuples per lane (256 per wave) with all loads of one kind issued back to back --
-// 4 probe rows, 4 keys, 4 bucket probes in flight per lane -- so a wave pays the sel -> key -> bucket
-// latency chain once per 256 tuples instead of once per 64.  Only for a stage-0 join that yields at most
-// one match per tuple (perfect table, unique-key table): matches go straight to queue 1 (capacity 320).
-template <int W, int K>
-__device__ __forceinline__ void run_stage0_wide(WaveCtx<W, K> &c) {
-	const Stage s = load_stage(&c.desc[0]);
-	const uint64_t left = c.in_end - c.in_pos;
-	const uint32_t n = left < 64 * WIDE ? (uint32_t)left : 64u * WIDE;
-	uint32_t row[WIDE];
+// Wide step: 4 tuples per lane (256 per wave) with all loads of one kind issued back to back -- 4 rows, 4 keys,
+// 4 slot-group probes in flight per lane -- so a wave pays the (sel ->) key -> bucket latency chain once per 256
+// tuples instead of once per 64.  Stage 0 reads the source, a deeper stage the top of its queue (sub-batch i =
+// the i-th 64 entries from the top, so whatever is not consumed stays in place at the bottom).  Allowed where
+// the matches have somewhere to go: stage 0 (queue 1 holds 63 + 256) and the last stage (output chunks).
+// Tables with repeated keys: if some key of the step repeats, the whole step (up to 256 tuples) is pinned --
+// stage 0: its rows in batch0; deeper: its queue cells stay in place -- with start / prefix-summed run lengths
+// in the wide pending area, and expanded 64 outputs at a time by resume_expansion_wide, deepest stage first.
+template <int W, int K, int POS>
+__device__ __forceinline__ void resume_expansion_wide(WaveCtx<W, K> &c);
+
+template <int W, int K, int POS>
+__device__ __forceinline__ void run_stage_wide(WaveCtx<W, K> &c) {
+	const Stage s = load_stage(&c.desc[POS]);
+	uint32_t n, qs = 0, base = 0;
+	if (POS == 0) {
+		const uint64_t left = c.in_end - c.in_pos;
+		n = left < 64 * WIDE ? (uint32_t)left : 64u * WIDE;
+	} else {
+		qs = c.qsize[POS];
+		n = qs < 64 * WIDE ? qs : 64u * WIDE;
+		base = qs - n;
+	}
+	Tuple<W> t[WIDE];
 	bool act[WIDE];
 #pragma unroll
 	for (int i = 0; i < WIDE; i++) {
-		const uint32_t off = c.lane + 64u * i;
-		act[i] = off < n;
-		const uint64_t tp = c.in_pos + off;
-		row[i] = act[i] ? (c.sel ? c.sel[tp] : (uint32_t)tp) : 0u;
+#pragma unroll
+		for (int q = 0; q < W; q++) {
+			t[i].s[q] = 0;
+		}
+		if (POS == 0) {
+			const uint32_t off = c.lane + 64u * i;
+			act[i] = off < n;
+			const uint64_t tp = c.in_pos + off;
+			t[i].s[0] = act[i] ? (c.sel ? c.sel[tp] : (uint32_t)tp) : 0u;
+		} else {
+			const int32_t idx = (int32_t)qs - 64 * (i + 1) + (int32_t)c.lane;
+			act[i] = idx >= (int32_t)base;
+			if (act[i]) {
+				const uint32_t *qq = c.q + qoff<W, POS>();
+#pragma unroll
+				for (int q = 0; q < W; q++) {
+					t[i].s[q] = qq[q * qcap<POS>() + idx];
+				}
+			}
+		}
 	}
-	c.in_pos += n;
 	uint64_t key[WIDE];
 	bool valid[WIDE];
 #pragma unroll
 	for (int i = 0; i < WIDE; i++) {
-		Tuple<W> t;
-#pragma unroll
-		for (int q = 0; q < W; q++) {
-			t.s[q] = 0;
-		}
-		t.s[0] = row[i];
-		valid[i] = fetch_key<W>(s, t, act[i], key[i]);
+		valid[i] = fetch_key<W>(s, t[i], act[i], key[i]);
 	}
 	uint32_t id[WIDE];
 	bool hit[WIDE];
+	bool multi[WIDE];
+	uint32_t start[WIDE], cnt[WIDE];
+#pragma unroll
+	for (int i = 0; i < WIDE; i++) {
+		multi[i] = false;
+		start[i] = cnt[i] = 0;
+	}
 	if (s.kind == KIND_PERFECT) {
 #pragma unroll
 		for (int i = 0; i < WIDE; i++) {
@@ -598,24 +654,177 @@ __device__ __forceinline__ void run_stage0_wide(WaveCtx<W, K> &c) {
 			id[i] = p[i].id;
 		}
 	} else {
-		// unique-key {key,start,count} table: count is 0 or 1
+		const uint4 *tab = (const uint4 *)s.table;
+		S16Probe p[WIDE];
+		bool any = false;
 #pragma unroll
 		for (int i = 0; i < WIDE; i++) {
-			uint32_t start, count;
-			lookup_s16(s, key[i], valid[i], start, count);
-			hit[i] = count != 0;
-			id[i] = (hit[i] && s.out_slot >= 0) ? s.rowids[start] : 0u;
+			s16_begin(s, key[i], valid[i], p[i]);
+			any = any || p[i].searching;
+		}
+		while (any) {
+			uint4 e0[WIDE], e1[WIDE];
+#pragma unroll
+			for (int i = 0; i < WIDE; i++) {
+				if (p[i].searching) {
+					e0[i] = tab[p[i].group * 2];
+					e1[i] = tab[p[i].group * 2 + 1];
+				}
+			}
+			any = false;
+#pragma unroll
+			for (int i = 0; i < WIDE; i++) {
+				if (p[i].searching) {
+					s16_check(s, p[i], e0[i], e1[i]);
+				}
+				any = any || p[i].searching;
+			}
+		}
+		// row ids of the single matches: one more hop, all sub-batches at once
+#pragma unroll
+		for (int i = 0; i < WIDE; i++) {
+			hit[i] = p[i].count != 0;
+			start[i] = p[i].start;
+			cnt[i] = p[i].count;
+			multi[i] = __ballot(p[i].count > 1) != 0ull;
+			id[i] = (hit[i] && s.out_slot >= 0) ? s.rowids[p[i].start] : 0u;
 		}
 	}
+	bool any_multi = false;
 #pragma unroll
 	for (int i = 0; i < WIDE; i++) {
-		Tuple<W> t;
+		any_multi = any_multi || multi[i];
+	}
+	if (POS == 0) {
+		c.in_pos += n;
+	} else {
+		c.qsize[POS] = base; // popped (a pinned step's cells stay in place below the new top)
+	}
+	if (!any_multi) {
 #pragma unroll
-		for (int q = 0; q < W; q++) {
-			t.s[q] = 0;
+		for (int i = 0; i < WIDE; i++) {
+			if (64u * i < n) {
+				emit_tuples<W, K, POS>(c, s, t[i], id[i], hit[i]);
+			}
 		}
-		t.s[0] = row[i];
-		emit_tuples<W, K, 0>(c, s, t, id[i], hit[i]);
+		return;
+	}
+	// pin the step and start its expansion
+	constexpr int SLOT = POS == 0 ? 0 : 1;
+	uint32_t *wst = c.wpend_start + SLOT * 64 * WIDE;
+	uint32_t *wpf = c.wpend_pref + SLOT * 64 * WIDE;
+	uint32_t carry = 0;
+#pragma unroll
+	for (int i = 0; i < WIDE; i++) {
+		const uint32_t pref = carry + wave_inclusive_scan(cnt[i], c.lane);
+		wst[i * 64 + c.lane] = start[i];
+		wpf[i * 64 + c.lane] = pref;
+		carry = uni(__shfl(pref, 63, 64));
+		if (POS == 0) {
+			c.batch0[i * 64 + c.lane] = t[i].s[0];
+		}
+	}
+	if (POS != 0) {
+		c.pend_base[POS] = qs;
+	}
+	c.pend_T[POS] = carry;
+	c.pend_cur[POS] = 0;
+	c.pend_wide |= 1u << POS;
+	resume_expansion_wide<W, K, POS>(c);
+}
+
+// continue the pending expansion of a pinned wide step of stage POS: the next <= 256 (tuple, build row)
+// pairs, 4 per lane, their row-id loads in flight together (one hop per 256 outputs instead of per 64)
+template <int W, int K, int POS>
+__device__ __forceinline__ void resume_expansion_wide(WaveCtx<W, K> &c) {
+	const Stage s = load_stage(&c.desc[POS]);
+	constexpr int SLOT = POS == 0 ? 0 : 1;
+	const uint32_t *wst = c.wpend_start + SLOT * 64 * WIDE;
+	const uint32_t *wpf = c.wpend_pref + SLOT * 64 * WIDE;
+	const uint32_t T = c.pend_T[POS];
+	const uint32_t cur = c.pend_cur[POS];
+	uint32_t src[WIDE], pos[WIDE];
+	bool valid[WIDE];
+#pragma unroll
+	for (int j = 0; j < WIDE; j++) {
+		const uint32_t o = cur + 64u * j + c.lane;
+		valid[j] = o < T;
+		uint32_t lo = 0, hi = 64 * WIDE - 1; // smallest entry with prefix > o
+		if (valid[j]) {
+#pragma unroll
+			for (int it = 0; it < 8; it++) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (wpf[mid] > o) {
+					hi = mid;
+				} else {
+					lo = mid + 1;
+				}
+			}
+		}
+		src[j] = valid[j] ? lo : 0;
+		const uint32_t excl = src[j] > 0 ? wpf[src[j] - 1] : 0;
+		pos[j] = wst[src[j]] + (o - excl);
+	}
+	uint32_t id[WIDE];
+#pragma unroll
+	for (int j = 0; j < WIDE; j++) {
+		id[j] = (valid[j] && s.out_slot >= 0) ? s.rowids[pos[j]] : 0u;
+	}
+#pragma unroll
+	for (int j = 0; j < WIDE; j++) {
+		if (cur + 64u * j < T) { // (wave-uniform)
+			Tuple<W> t;
+#pragma unroll
+			for (int i = 0; i < W; i++) {
+				t.s[i] = 0;
+			}
+			if (POS == 0) {
+				t.s[0] = c.batch0[src[j]];
+			} else if (valid[j]) {
+				// entry (sub-batch i, lane l) of the step sits at queue index top - 64 (i + 1) + l
+				const uint32_t idx = c.pend_base[POS] - 64u * ((src[j] >> 6) + 1) + (src[j] & 63u);
+				const uint32_t *qq = c.q + qoff<W, POS>();
+#pragma unroll
+				for (int i = 0; i < W; i++) {
+					t.s[i] = qq[i * qcap<POS>() + idx];
+				}
+			}
+			emit_tuples<W, K, POS>(c, s, t, id[j], valid[j]);
+		}
+	}
+	if (cur + 64u * WIDE >= T) {
+		c.pend_T[POS] = 0;
+		c.pend_cur[POS] = 0;
+		c.pend_wide &= ~(1u << POS);
+	} else {
+		c.pend_cur[POS] = cur + 64u * WIDE;
+	}
+}
+
+template <int W, int K, int POS>
+__device__ __forceinline__ void dispatch_resume_wide(WaveCtx<W, K> &c, int pick) {
+	if (pick == POS) {
+		if constexpr (POS == 0 || (K <= 4 && W <= 4)) {
+			resume_expansion_wide<W, K, POS>(c);
+		}
+		return;
+	}
+	if constexpr (POS + 1 < K) {
+		dispatch_resume_wide<W, K, POS + 1>(c, pick);
+	}
+}
+
+// wide steps exist for stage 0 and -- for pipelines of up to 4 stages carrying up to 4 ids -- for the last stage
+template <int W, int K, int POS>
+__device__ __forceinline__ void dispatch_wide(WaveCtx<W, K> &c, int pick) {
+	if (pick == POS) {
+		if constexpr (POS == 0 || (K <= 4 && W <= 4)) {
+			run_stage_wide<W, K, POS>(c);
+		}
+		return;
+	}
+	if constexpr (POS + 1 < K) {
+		dispatch_wide<W, K, POS + 1>(c, pick);
 	}
 }
 
@@ -632,6 +841,18 @@ __device__ __forceinline__ void dispatch(WaveCtx<W, K> &c, int pick, bool resume
 	if constexpr (POS + 1 < K) {
 		dispatch<W, K, POS + 1>(c, pick, resume);
 	}
+}
+
+// which stages of the join order whose descriptors start at `src` may take wide steps
+template <int W, int K>
+__device__ __forceinline__ uint32_t stage_wide_mask(const uint32_t *src, uint32_t k) {
+	uint32_t m = uni(src[offsetof(StageDesc, unique) / 4]) != 0 ? 1u : 0u;
+	if constexpr (K <= 4 && W <= 4) {
+		if (k > 1 && uni(src[(k - 1) * STAGE_DESC_DWORDS + offsetof(StageDesc, unique) / 4]) != 0) {
+			m |= 1u << (k - 1);
+		}
+	}
+	return m;
 }
 
 // scheduler: run until the unit's input is consumed and no stage holds a full batch or a pending
@@ -667,8 +888,10 @@ __device__ __forceinline__ void run_until_idle(WaveCtx<W, K> &c, bool flushing) 
 		if (pick < 0) {
 			return;
 		}
-		if (pick == 0 && !resume && c.wide0) {
-			run_stage0_wide<W, K>(c);
+		if (resume && ((c.pend_wide >> pick) & 1u)) {
+			dispatch_resume_wide<W, K, 0>(c, pick);
+		} else if (!resume && ((c.wide_mask >> pick) & 1u)) {
+			dispatch_wide<W, K, 0>(c, pick);
 		} else {
 			dispatch<W, K, 0>(c, pick, resume);
 		}
@@ -733,12 +956,12 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	}
 	if (b == 0) {
 		if (wave_in_block == 0) {
-			const uint32_t dyn_dwords = wpb * (K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64);
+			const uint32_t dyn_dwords = wpb * per_wave_dwords<W, K>();
 			polr_resident_router(x, k, n_workers, threadIdx.x & 63, router_lds, (uint64_t *)lds, dyn_dwords / 2);
 		}
 		return;
 	}
-	const uint32_t per_wave = K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64;
+	const uint32_t per_wave = per_wave_dwords<W, K>();
 	WaveCtx<W, K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
@@ -748,13 +971,16 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	c.pend_start = c.q + qtotal<W, K>();
 	c.pend_pref = c.pend_start + K * 64;
 	c.batch0 = c.pend_pref + K * 64;
+	c.wpend_start = c.batch0 + 64 * WIDE;
+	c.wpend_pref = c.wpend_start + 2 * 64 * WIDE;
 #pragma unroll
 	for (int p = 0; p < K; p++) {
 		c.qsize[p] = c.pend_T[p] = c.pend_cur[p] = c.pend_base[p] = c.cnt[p] = 0;
 	}
 	c.sel = uniptr(pipe->sel);
 	c.in_pos = c.in_end = 0;
-	c.wide0 = false;
+	c.wide_mask = 0;
+	c.pend_wide = 0;
 	c.flush_token = 0;
 	c.out = out;
 	c.emit = false;
@@ -824,7 +1050,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 				dst[i] = src[i];
 			}
 			c.emit = emit && !c.overflow;
-			c.wide0 = uni(src[offsetof(StageDesc, unique) / 4]) != 0;
+			c.wide_mask = stage_wide_mask<W, K>(src, c.k);
 			uint32_t my_units = 0;
 			for (uint32_t unit = rank; unit < n_units; unit += n_workers) {
 				c.in_pos = rb + (uint64_t)unit * us;
@@ -891,7 +1117,7 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 		return;
 	}
 	const uint32_t k = uni(pipe->k);
-	const uint32_t per_wave = K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64;
+	const uint32_t per_wave = per_wave_dwords<W, K>();
 	WaveCtx<W, K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
@@ -901,13 +1127,16 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 	c.pend_start = c.q + qtotal<W, K>();
 	c.pend_pref = c.pend_start + K * 64;
 	c.batch0 = c.pend_pref + K * 64;
+	c.wpend_start = c.batch0 + 64 * WIDE;
+	c.wpend_pref = c.wpend_start + 2 * 64 * WIDE;
 #pragma unroll
 	for (int p = 0; p < K; p++) {
 		c.qsize[p] = c.pend_T[p] = c.pend_cur[p] = c.pend_base[p] = c.cnt[p] = 0;
 	}
 	c.sel = uniptr(pipe->sel);
 	c.in_pos = c.in_end = 0;
-	c.wide0 = false;
+	c.wide_mask = 0;
+	c.pend_wide = 0;
 	c.flush_token = 0;
 	c.out = out;
 	c.emit = false;
@@ -944,7 +1173,7 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 				dst[i] = src[i];
 			}
 			c.emit = uni(rounds[r].emit) != 0 && !c.overflow;
-			c.wide0 = uni(src[offsetof(StageDesc, unique) / 4]) != 0;
+			c.wide_mask = stage_wide_mask<W, K>(src, c.k);
 		}
 		const uint64_t rb = uni64(rounds[r].begin);
 		const uint64_t rc = uni64(rounds[r].count);
@@ -1008,7 +1237,7 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 
 static size_t lds_bytes_k(uint32_t W, uint32_t waves_per_block) {
 	const size_t queues = POLR_K <= 1 ? 0 : (size_t)W * QCAP1 + (size_t)(POLR_K - 2) * W * QCAPN;
-	return (size_t)waves_per_block * ((size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64) *
+	return (size_t)waves_per_block * ((size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64 * WIDE + 2 * 64 * WIDE * 2) *
 	           sizeof(uint32_t) +
 	       64; // + the static arrival flag of a self-routing launch
 }
