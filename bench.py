@@ -166,6 +166,9 @@ def main():
                     help="resident: the whole pass is ONE launch (device-resident routing loop, "
                          "polr_mpx_run_resident); rounds: one self-routing launch per routing round "
                          "(polr_mpx_run / _run_many)")
+    ap.add_argument("--host-filter", action="store_true",
+                    help="upload the host-computed selection instead of running the pushed-down filter of the source "
+                         "scan on the device (polr_pipeline_scan_filter); either way it happens before the clock starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -243,21 +246,46 @@ def main():
     pipe = capi.Pipeline(ctx, cols, n_rows, joins, paths)
     sel = probe.get("filter_sel")
     sel_t = None
-    if sel is not None:
-        sel_t = torch.from_numpy(np.ascontiguousarray(sel)).to(dev)
-        pipe.set_selection(sel_t.data_ptr(), device=True, n=len(sel))
-    n_tuples = len(sel) if sel is not None else n_rows
+    scan_info = None
+    device_scan = bool(probe.get("filter")) and not args.host_filter
+    if device_scan:
+        # source side on the device: the pushed-down filter of the table scan thins the
+        # 1024-row vectors into the chunks the multiplexer sees; selection and chunk boundaries stay in HBM
+        flt = [(names.index(c), op, const) for c, op, const in probe["filter"]]
+        best = None
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            n_tuples, n_chunks = pipe.scan_filter(flt, vector_size=V)
+            dt_s = time.perf_counter() - t_s
+            best = dt_s if best is None else min(best, dt_s)
+        scan_bytes = 2 * sum(probe["cols"][c].dtype.itemsize for c, _, _ in probe["filter"]) * n_rows + 4 * n_tuples
+        scan_info = {"rows": n_rows, "selected": int(n_tuples), "chunks": int(n_chunks),
+                     "ms": round(best * 1e3, 4), "algorithmic_bytes": int(scan_bytes),
+                     "GB/s": round(scan_bytes / best / 1e9, 1),
+                     "note": "whole call incl. two synchronisations and the result allocation; outside the timed region"}
+        if sel is not None and n_tuples != len(sel):
+            raise SystemExit("device scan selected %d rows, the workload's host filter %d" % (n_tuples, len(sel)))
+        offs = None
+    else:
+        if sel is not None:
+            sel_t = torch.from_numpy(np.ascontiguousarray(sel)).to(dev)
+            pipe.set_selection(sel_t.data_ptr(), device=True, n=len(sel))
+        n_tuples = len(sel) if sel is not None else n_rows
     budget = args.regret_budget
     if args.routing == "exponential_backoff":
         budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
-    offs = chunk_offsets_for(sel, n_rows, V)
-    n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
+    if not device_scan:
+        offs = chunk_offsets_for(sel, n_rows, V)
+        n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
     E = max(1, min(args.executors, n_chunks))
     execs = []
     for e in range(E):
         m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
                                    init_tuple_count=args.init_tuple_count, log_rounds=False)
-        if offs is not None:
+        if device_scan:
+            m.use_scan_chunks()
+        elif offs is not None:
             m.set_chunk_offsets(offs)
         execs.append((m, None, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
     results = [None] * E
@@ -382,7 +410,7 @@ def main():
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],
             "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info,
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)

@@ -1083,6 +1083,11 @@ int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t 
 	}
 	p->sel_dev = nullptr;
 	p->sel_owned = false;
+	if (p->scan_offsets_dev) { // a caller-given selection replaces a scan result
+		hipFree(p->scan_offsets_dev);
+		p->scan_offsets_dev = nullptr;
+		p->scan_n_chunks = 0;
+	}
 	if (!sel) {
 		p->n_tuples = p->n_probe_rows;
 	} else {
@@ -1159,6 +1164,9 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	}
 	if (p->sel_dev && p->sel_owned) {
 		hipFree(p->sel_dev);
+	}
+	if (p->scan_offsets_dev) {
+		hipFree(p->scan_offsets_dev);
 	}
 	if (p->dev_mat) {
 		hipFree(p->dev_mat);

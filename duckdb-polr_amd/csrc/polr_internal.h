@@ -62,6 +62,10 @@ struct polr_pipeline {
 	DevCol *probe_cols_dev = nullptr;
 	uint32_t *sel_dev = nullptr;
 	bool sel_owned = false;
+	// result of polr_pipeline_scan_filter: boundaries of the (non-empty) source chunks in selection positions
+	uint64_t *scan_offsets_dev = nullptr;
+	uint64_t scan_n_chunks = 0;
+	uint32_t scan_vector_size = 0;
 	std::vector<polr_ht *> hts;
 	DevPipeline host_count, host_mat; // count-only (narrow tuples) and materialising (all ids) variants
 	DevPipeline *dev_count = nullptr, *dev_mat = nullptr;

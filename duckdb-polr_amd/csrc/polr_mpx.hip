@@ -35,6 +35,7 @@ struct polr_mpx {
 	uint32_t iter = 0; // launches of the path kernel so far (descriptor slot = iter & 1)
 	unsigned long long *counts_dev = nullptr;
 	uint64_t *chunk_offsets_dev = nullptr;
+	bool chunk_offsets_owned = true; // false: the pipeline's scan result
 	uint32_t *log_path = nullptr;
 	uint64_t *log_tuples = nullptr, *log_inter = nullptr;
 	uint32_t *done_host = nullptr;        // pinned, mapped: [0] routing steps completed, [1] done
@@ -241,10 +242,11 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 	}
 	polr_ctx *ctx = m->pipe->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	if (m->chunk_offsets_dev) {
+	if (m->chunk_offsets_dev && m->chunk_offsets_owned) {
 		hipFree(m->chunk_offsets_dev);
-		m->chunk_offsets_dev = nullptr;
 	}
+	m->chunk_offsets_dev = nullptr;
+	m->chunk_offsets_owned = true;
 	if (!offsets) {
 		m->n_chunks = (m->pipe->n_tuples + m->cfg.chunk_size - 1) / m->cfg.chunk_size;
 		return POLR_OK;
@@ -258,6 +260,26 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 	HIPCHK(ctx, hipMalloc((void **)&m->chunk_offsets_dev, (n_chunks + 1) * 8));
 	HIPCHK(ctx, hipMemcpy(m->chunk_offsets_dev, offsets, (n_chunks + 1) * 8, hipMemcpyHostToDevice));
 	m->n_chunks = n_chunks;
+	return POLR_OK;
+}
+
+// the source chunks are the ones polr_pipeline_scan_filter produced (boundaries stay on the device)
+int polr_mpx_use_scan_chunks(polr_mpx *m) {
+	if (!m) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = m->pipe;
+	polr_ctx *ctx = p->ctx;
+	if (!p->scan_offsets_dev) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "no scan result: call polr_pipeline_scan_filter first");
+	}
+	if (m->chunk_offsets_dev && m->chunk_offsets_owned) {
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		hipFree(m->chunk_offsets_dev);
+	}
+	m->chunk_offsets_dev = p->scan_offsets_dev;
+	m->chunk_offsets_owned = false;
+	m->n_chunks = p->scan_n_chunks;
 	return POLR_OK;
 }
 
@@ -749,7 +771,7 @@ void polr_mpx_destroy(polr_mpx *m) {
 	if (m->counts_dev) {
 		hipFree(m->counts_dev);
 	}
-	if (m->chunk_offsets_dev) {
+	if (m->chunk_offsets_dev && m->chunk_offsets_owned) {
 		hipFree(m->chunk_offsets_dev);
 	}
 	if (m->log_path) {

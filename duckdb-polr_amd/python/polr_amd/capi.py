@@ -30,6 +30,7 @@ EXPORTS = [
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
+    "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks",
 ]
 
 
@@ -50,6 +51,13 @@ class JoinDesc(C.Structure):
 
 class Round(C.Structure):
     _fields_ = [("begin", C.c_uint64), ("count", C.c_uint64), ("path", C.c_uint32), ("emit", C.c_uint32)]
+
+
+class ScanFilter(C.Structure):
+    _fields_ = [("col", C.c_uint32), ("op", C.c_uint32), ("constant", C.c_int64)]
+
+
+CMP = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, ">": 3, "<=": 4, ">=": 5, "is null": 6, "is not null": 7}
 
 
 class HtInfo(C.Structure):
@@ -124,6 +132,9 @@ def load():
     L.polr_mpx_reset.argtypes = [vp, vp]
     L.polr_mpx_run_many.argtypes = [vp, vp, vp, vp, u32, vp]
     L.polr_mpx_finish_many.argtypes = [vp, u32, vp]
+    L.polr_pipeline_scan_filter.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.polr_pipeline_fetch_scan.argtypes = [vp, vp, vp]
+    L.polr_mpx_use_scan_chunks.argtypes = [vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
@@ -306,6 +317,26 @@ class Pipeline:
             sel = np.ascontiguousarray(sel, dtype=np.uint32)
             self.ctx.check(self.ctx.L.polr_pipeline_set_selection(self.h, sel.ctypes.data, len(sel), 0))
 
+    def scan_filter(self, filters, vector_size=1024, stream=None):
+        """polr_pipeline_scan_filter: filters = [(col, op, constant)] with op in CMP; the selection and the chunk
+        boundaries stay on the device -> (n_selected, n_chunks)"""
+        n = len(filters)
+        arr = (ScanFilter * max(n, 1))()
+        for i, (col, op, const) in enumerate(filters):
+            arr[i].col, arr[i].op, arr[i].constant = col, CMP[op] if isinstance(op, str) else op, int(const or 0)
+        ns, nc = C.c_uint64(), C.c_uint64()
+        self.ctx.check(self.ctx.L.polr_pipeline_scan_filter(self.h, stream, arr if n else None, n, vector_size,
+                                                            C.byref(ns), C.byref(nc)))
+        self.scan = (ns.value, nc.value)
+        return self.scan
+
+    def fetch_scan(self):
+        ns, nc = self.scan
+        sel = np.zeros((ns,), dtype=np.uint32)
+        offs = np.zeros((nc + 1,), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.polr_pipeline_fetch_scan(self.h, sel.ctypes.data, offs.ctypes.data))
+        return sel, offs
+
     def probe_rounds(self, rounds, out=None, stream=None):
         """rounds: [(begin, count, path, emit)] -> counts ndarray [n_rounds, k]"""
         n = len(rounds)
@@ -399,6 +430,10 @@ class DeviceMultiplexer:
     def set_chunk_offsets(self, offsets):
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.ctx.check(self.ctx.L.polr_mpx_set_chunk_offsets(self.h, offsets.ctypes.data, len(offsets) - 1))
+
+    def use_scan_chunks(self):
+        """source chunks = the pipeline's scan_filter result (device-resident boundaries)"""
+        self.ctx.check(self.ctx.L.polr_mpx_use_scan_chunks(self.h))
 
     def run(self, chunk_begin, chunk_end, out=None, stream=None):
         self.ctx.check(self.ctx.L.polr_mpx_run(self.h, stream, chunk_begin, chunk_end, out.h if out else None))

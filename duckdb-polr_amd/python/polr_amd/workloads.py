@@ -170,7 +170,8 @@ def job_light_01(scale=1.0, seed=SEED):
     mc_sel = np.nonzero(mc_ctype == 2)[0].astype(np.uint32)
     mi_keep = mi_type == 112
     probe = {"name": "movie_companies", "cols": {"movie_id": mc_movie, "company_type_id": mc_ctype},
-             "filter_sel": mc_sel, "filter_sql": "company_type_id=2"}
+             "filter_sel": mc_sel, "filter_sql": "company_type_id=2",
+             "filter": [("company_type_id", "=", 2)]}
     jt = {"name": "title", "keys": [t_id], "key_names": ["id"], "payload": {}, "key_src": [(-1, 0)], "perfect": None}
     jmi = {"name": "movie_info_idx", "keys": [mi_movie[mi_keep]], "key_names": ["movie_id"], "payload": {},
            "key_src": [(-1, 0)], "perfect": None,

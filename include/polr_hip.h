@@ -156,6 +156,31 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
  * chunks (DICTIONARY/sliced vectors, vector.hpp:36-140): sel[i] = probe-table row.  NULL resets
  * to "all rows".  flags: POLR_COL_DEVICE if sel is a device pointer. */
 int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t n_sel, uint32_t flags);
+
+/* ---- source side on the device ---------------------------------------
+ * PhysicalTableScan with pushed-down table filters: the table is scanned in vectors of `vector_size`
+ * rows (STANDARD_VECTOR_SIZE), every vector is thinned to the rows that pass ALL filters, in row order;
+ * a vector without a survivor yields no chunk; NULL passes no comparison
+ * (src/storage/table/row_group.cpp:316-452 RowGroup::TemplatedScan, src/storage/table/column_segment.cpp:194-475
+ * FilterSelection; filter classes src/include/duckdb/planner/filter/{constant,null,conjunction}_filter.hpp).
+ * The result -- selection (ascending probe-table rows) and the boundaries of the non-empty chunks --
+ * stays in HBM and becomes the pipeline's source (as polr_pipeline_set_selection would install it);
+ * multiplexers take the boundaries with polr_mpx_use_scan_chunks.  n_filters == 0: every row passes.
+ * A negative constant against an unsigned column is POLR_E_INVALID; OR-conjunctions are not pushed
+ * down on this path (POLR_E_UNSUPPORTED would be the caller's: keep them in a host filter). */
+enum {
+	POLR_CMP_EQ = 0, POLR_CMP_NE = 1, POLR_CMP_LT = 2, POLR_CMP_GT = 3, POLR_CMP_LE = 4, POLR_CMP_GE = 5,
+	POLR_CMP_IS_NULL = 6, POLR_CMP_IS_NOT_NULL = 7
+};
+typedef struct polr_scan_filter {
+	uint32_t col;     /* probe-table column */
+	uint32_t op;      /* POLR_CMP_* (ConstantFilter::comparison_type / IsNullFilter / IsNotNullFilter) */
+	int64_t constant; /* ConstantFilter::constant, widened */
+} polr_scan_filter;
+int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_filter *filters, uint32_t n_filters,
+                              uint32_t vector_size, uint64_t *n_selected, uint64_t *n_chunks);
+/* read the scan result back (tests): sel[n_selected], chunk_offsets[n_chunks + 1]; either may be NULL */
+int polr_pipeline_fetch_scan(polr_pipeline *p, uint32_t *sel, uint64_t *chunk_offsets);
 /* Refresh the cells of probe column `col` in place (a new DataChunk arriving at the operator-level
  * drop-in, PhysicalHashJoin::Execute physical_hash_join.cpp:637-681): n_rows <= the row count the
  * pipeline was created with; becomes the new tuple count.  Only for columns the library owns (created
@@ -234,6 +259,8 @@ typedef struct polr_mpx_stats {
 } polr_mpx_stats;
 
 int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out);
+/* the source chunks are those of the pipeline's polr_pipeline_scan_filter result (boundaries stay in HBM) */
+int polr_mpx_use_scan_chunks(polr_mpx *m);
 /* Route and probe source chunks [chunk_begin, chunk_end) (chunk c = tuples [c*chunk_size, ...)
  * unless chunk offsets were set) entirely on the device; asynchronous. */
 int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out);

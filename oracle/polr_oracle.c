@@ -1867,3 +1867,110 @@ void orc_bindings(int k, int n_probe_cols, const int32_t *num_build_cols, const 
 		}
 	}
 }
+
+/* ---- table scan with pushed-down filters (row_group.cpp:316-452, column_segment.cpp:194-475) ---- */
+static int64_t orc_cell_i64(const orc_col_t *c, idx_t row) {
+	const uint8_t *p = (const uint8_t *)c->data + row * (idx_t)c->width;
+	switch (c->width) {
+	case 1:
+		return c->is_signed ? (int64_t) * (const int8_t *)p : (int64_t) * (const uint8_t *)p;
+	case 2: {
+		uint16_t v;
+		memcpy(&v, p, 2);
+		return c->is_signed ? (int64_t)(int16_t)v : (int64_t)v;
+	}
+	case 4: {
+		uint32_t v;
+		memcpy(&v, p, 4);
+		return c->is_signed ? (int64_t)(int32_t)v : (int64_t)v;
+	}
+	default: {
+		int64_t v;
+		memcpy(&v, p, 8);
+		return v;
+	}
+	}
+}
+
+static int orc_compare(const orc_col_t *c, idx_t row, int op, int64_t constant) {
+	/* OP::Operation(vec[idx], *predicate) on the column's physical type (FilterSelectionSwitch :208-300);
+	 * an unsigned 64-bit column compares unsigned */
+	if (c->width == 8 && !c->is_signed) {
+		uint64_t v;
+		memcpy(&v, (const uint8_t *)c->data + row * 8, 8);
+		const uint64_t k = (uint64_t)constant;
+		switch (op) {
+		case ORC_CMP_EQ:
+			return v == k;
+		case ORC_CMP_NE:
+			return v != k;
+		case ORC_CMP_LT:
+			return v < k;
+		case ORC_CMP_GT:
+			return v > k;
+		case ORC_CMP_LE:
+			return v <= k;
+		default:
+			return v >= k;
+		}
+	}
+	const int64_t v = orc_cell_i64(c, row);
+	switch (op) {
+	case ORC_CMP_EQ:
+		return v == constant;
+	case ORC_CMP_NE:
+		return v != constant;
+	case ORC_CMP_LT:
+		return v < constant;
+	case ORC_CMP_GT:
+		return v > constant;
+	case ORC_CMP_LE:
+		return v <= constant;
+	default:
+		return v >= constant;
+	}
+}
+
+idx_t orc_scan_filter(const orc_col_t *cols, idx_t n_rows, const orc_filter_t *filters, int n_filters,
+                      idx_t vector_size, uint32_t *sel, idx_t *n_sel, idx_t *chunk_offsets) {
+	idx_t n_chunks = 0, out = 0;
+	uint32_t *approved = (uint32_t *)malloc(sizeof(uint32_t) * (vector_size ? vector_size : 1));
+	for (idx_t current_row = 0; current_row < n_rows; current_row += vector_size) { /* row_group.cpp:323-329 */
+		const idx_t max_count = n_rows - current_row < vector_size ? n_rows - current_row : vector_size;
+		idx_t approved_tuple_count = max_count; /* :375 (no deletions: count == max_count) */
+		for (idx_t i = 0; i < max_count; i++) {
+			approved[i] = (uint32_t)i;
+		}
+		for (int f = 0; f < n_filters; f++) { /* :388-394: one Select per filter column, each thins `sel` */
+			const orc_col_t *c = &cols[filters[f].col];
+			idx_t result_count = 0;
+			for (idx_t i = 0; i < approved_tuple_count; i++) { /* column_segment.cpp:198-204 */
+				const idx_t idx = current_row + approved[i];
+				const int valid = !(c->valid && !c->valid[idx]);
+				int keep;
+				if (filters[f].op == ORC_CMP_IS_NULL) {
+					keep = !valid;
+				} else if (filters[f].op == ORC_CMP_IS_NOT_NULL) {
+					keep = valid;
+				} else {
+					keep = valid && orc_compare(c, idx, filters[f].op, filters[f].constant);
+				}
+				if (keep) {
+					approved[result_count++] = approved[i];
+				}
+			}
+			approved_tuple_count = result_count;
+		}
+		if (approved_tuple_count == 0) {
+			continue; /* :399-416: all rows filtered out, skip this vector */
+		}
+		chunk_offsets[n_chunks++] = out;
+		for (idx_t i = 0; i < approved_tuple_count; i++) {
+			sel[out++] = (uint32_t)(current_row + approved[i]);
+		}
+	}
+	chunk_offsets[n_chunks] = out;
+	*n_sel = out;
+	free(approved);
+	return n_chunks;
+}

@@ -151,6 +151,25 @@ void orc_result_free(orc_result_t *res);
 
 /* Output column materialisation for parity checks (join_hashtable.cpp:521-529,558-562 +
  * row_gather.cpp:16-86; perfect_hash_join_executor.cpp:200-206).  src_join = -1: probe column. */
+/* ---- source side: table scan with pushed-down filters ------------------------------------------
+ * RowGroup::TemplatedScan (src/storage/table/row_group.cpp:316-452): the table is read one vector of
+ * `vector_size` rows at a time; every pushed-down filter thins the vector's selection in turn
+ * (ColumnSegment::FilterSelection, src/storage/table/column_segment.cpp:304-475; a comparison keeps row idx iff
+ * mask.RowIsValid(idx) && OP(vec[idx], constant), TemplatedFilterSelection :194-206; IS [NOT] NULL
+ * TemplatedNullSelection); a vector whose selection runs empty is skipped (row_group.cpp:399-416), otherwise the
+ * survivors form one chunk, in row order.
+ * Output: sel[] = surviving rows (ascending), chunk_offsets[] = positions in sel where a chunk starts, plus
+ * the end; returns the number of chunks, *n_sel = survivors.  Both arrays must hold n_rows (+1) entries. */
+enum { ORC_CMP_EQ = 0, ORC_CMP_NE = 1, ORC_CMP_LT = 2, ORC_CMP_GT = 3, ORC_CMP_LE = 4, ORC_CMP_GE = 5,
+       ORC_CMP_IS_NULL = 6, ORC_CMP_IS_NOT_NULL = 7 };
+typedef struct orc_filter {
+	int32_t col;
+	int32_t op;
+	int64_t constant;
+} orc_filter_t;
+idx_t orc_scan_filter(const orc_col_t *cols, idx_t n_rows, const orc_filter_t *filters, int n_filters,
+                      idx_t vector_size, uint32_t *sel, idx_t *n_sel, idx_t *chunk_offsets);
+
 int orc_materialize_column(const uint32_t *out_rows, idx_t n_out, int k, int src_join, const orc_col_t *col,
                            uint8_t *dst_data, uint8_t *dst_valid);
 

@@ -62,6 +62,13 @@ class _Result(C.Structure):
 _lib = None
 
 
+class _Filter(C.Structure):
+    _fields_ = [("col", C.c_int32), ("op", C.c_int32), ("constant", C.c_int64)]
+
+
+CMP = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, ">": 3, "<=": 4, ">=": 5, "is null": 6, "is not null": 7}
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -122,6 +129,9 @@ def lib():
         L.orc_enumerate.restype = C.c_int
         L.orc_enumerate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_bindings.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(_Join), C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_scan_filter.restype = C.c_uint64
+        L.orc_scan_filter.argtypes = [C.POINTER(_Col), C.c_uint64, C.POINTER(_Filter), C.c_int, C.c_uint64, C.c_void_p,
+                                      C.POINTER(C.c_uint64), C.c_void_p]
         _lib = L
     return _lib
 
@@ -385,3 +395,21 @@ def bindings(n_probe_cols, num_build_cols, joins, paths):
     lib().orc_bindings(k, n_probe_cols, nb.ctypes.data, _joins_struct(joins), paths.ctypes.data, len(paths),
                        out.ctypes.data)
     return out
+
+
+def scan_filter(cols, filters, vector_size=1024, valids=None):
+    """table scan with pushed-down filters (RowGroup::TemplatedScan): cols = numpy arrays, filters =
+    [(col, op, constant)] -> (sel uint32[n_sel], chunk_offsets uint64[n_chunks + 1])"""
+    L = lib()
+    valids = valids or [None] * len(cols)
+    cs = _cols(list(zip(cols, valids)))
+    n_rows = len(cols[0])
+    fa = (_Filter * max(len(filters), 1))()
+    for i, (col, op, const) in enumerate(filters):
+        fa[i].col, fa[i].op, fa[i].constant = col, CMP[op] if isinstance(op, str) else op, int(const or 0)
+    sel = np.zeros((max(n_rows, 1),), dtype=np.uint32)
+    offs = np.zeros((n_rows + 2,), dtype=np.uint64)
+    n_sel = C.c_uint64()
+    n_chunks = L.orc_scan_filter(cs, n_rows, fa, len(filters), vector_size, sel.ctypes.data, C.byref(n_sel),
+                                 offs.ctypes.data)
+    return sel[:n_sel.value].copy(), offs[:n_chunks + 1].copy()
