@@ -183,8 +183,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # "nccl" is RCCL on ROCm.  POLR_DIST_BACKEND=gloo + POLR_SHARE_DEVICE=1 rehearse the N > 1 path on a
+        # one-GPU box (all ranks on cuda:0; RCCL refuses two ranks on one device)
+        backend = os.environ.get("POLR_DIST_BACKEND", "nccl")
+        if os.environ.get("POLR_SHARE_DEVICE"):
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)

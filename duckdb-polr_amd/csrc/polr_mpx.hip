@@ -538,6 +538,8 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 		ex[i].n_tuples = p->n_tuples;
 		ex[i].epoch = m->res_epoch;
 		ex[i].flags = flags;
+		ex[i].registered = 0;
+		ex[i].pad = 0;
 		ex[i].stats_out = m->stats_host_dev;
 		m->stats_in_host = (flags & POLR_RUN_FINISH) != 0;
 		ex[i].stamps = nullptr;

@@ -258,13 +258,18 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 // atomics -- no fences, no host.
 //
 //   word_a = epoch:12 | round:20 | count:32     count = tuples of the round; POLR_RES_DONE = run over
-//   word_b = tag:14 | emit:1 | path:5 | unit_size:12 | begin:32     tag = (epoch & 127) << 7 | (round & 127)
+//   word_b = tag:8 | n_blocks:12 | emit:1 | path:5 | unit_size/64:6 | begin:32
+//            tag = (epoch & 15) << 4 | (round & 15); n_blocks = worker workgroups the round is dealt to
 //
 // A worker waits for word_a to show its epoch and a round number other than the one it processed last,
-// then for word_b to carry the matching tag (the two stores need no order).  Units of a round are dealt
-// statically (unit u -> worker u mod n_workers), so only workers that own a unit of the round touch
-// anything else; they add the units they finished to `units_done` after their counter atomics have
-// returned.  The router waits for units_done to reach the running total, absorbs the counters, routes.
+// then for word_b to carry the matching tag (the two stores need no order).  Worker workgroups REGISTER when
+// they start (atomic counter, zeroed with the descriptor copy of every run): the registration order is their
+// rank, and the router deals the units of a round statically over the workgroups registered so far (unit u ->
+// workgroup u mod n_blocks, wave (u / n_blocks) mod waves).  Nothing ever waits for a workgroup that is not
+// running yet, so a device shared with other kernels (two resident runs at once, foreign work) only makes
+// rounds narrower, it cannot deadlock them.  Only workers that own a unit of the round touch anything but
+// their poll word; they add the units they finished to the arrival counter after their counter atomics have
+// returned.  The router waits for the arrivals to reach the running total, absorbs the counters, routes.
 #define POLR_RES_DONE 0xFFFFFFFFu
 #define POLR_RES_TIMEOUT_TICKS 400000000ull // 4 s of the 100 MHz wall clock: a wait this long is a lost run
 
@@ -288,6 +293,8 @@ struct ResidentExec {
 	uint64_t n_chunks, n_tuples;
 	uint32_t epoch; // 12 bits, host-incremented per run
 	uint32_t flags; // POLR_RUN_RESET | POLR_RUN_FINISH
+	uint32_t registered; // worker workgroups of this executor that have started (zero when the run is enqueued)
+	uint32_t pad;
 	polr_mpx_stats *stats_out; // POLR_RUN_FINISH: where the closing statistics go (pinned host memory)
 	unsigned long long *stamps; // diagnostic builds only (POLR_DIAG_STAMPS), else nullptr
 };
@@ -308,7 +315,7 @@ __device__ __forceinline__ unsigned long long polr_res_word_a(uint32_t epoch, ui
 	return ((unsigned long long)(epoch & 0xFFFu) << 52) | ((unsigned long long)(round & 0xFFFFFu) << 32) | count;
 }
 __device__ __forceinline__ uint32_t polr_res_tag(uint32_t epoch, uint32_t round) {
-	return ((epoch & 127u) << 7) | (round & 127u);
+	return ((epoch & 15u) << 4) | (round & 15u);
 }
 __device__ __forceinline__ uint32_t polr_res_next_round(uint32_t round) {
 	round = (round + 1) & 0xFFFFFu;
@@ -380,8 +387,9 @@ __device__ __forceinline__ void polr_offs_cache_fill(OffsCache &oc, const Reside
 
 // The router of one executor: ONE full wave, for the whole run.  lds: POLR_RES_ROUTER_DWORDS dwords.
 // cache_lds / cache_cap: the router workgroup's (otherwise unused) dynamic LDS, in 8-byte entries.
-__device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint32_t k, uint32_t n_workers,
-                                                     uint32_t lane, uint32_t *lds, uint64_t *cache_lds,
+// registered: the executor's registration counter; wpb: waves per worker workgroup.
+__device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint32_t k, uint32_t *registered,
+                                                     uint32_t wpb, uint32_t lane, uint32_t *lds, uint64_t *cache_lds,
                                                      uint32_t cache_cap) {
 	DevMpx *mg = x.mpx;
 	{
@@ -440,8 +448,23 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		if (lane == 0) {
 			RES_STAMP(x, n_steps, 0)
 		}
+		// the round is dealt to the worker workgroups that have started by now (at least one)
+		uint32_t n_blocks = 0;
+		{
+			const unsigned long long t0 = wall_clock64();
+			while (true) {
+				n_blocks = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (n_blocks != 0 || wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
+					break;
+				}
+				__builtin_amdgcn_s_sleep(2);
+			}
+			n_blocks = __shfl(n_blocks, 0, 64);
+			n_blocks = n_blocks > 4095u ? 4095u : n_blocks;
+		}
 		// (a reset run drops whatever the counters still hold: first step only)
-		polr_router_step_impl(m, mg, round, prefix, us, x.counts, k, n_workers, lane, true, &oc, reset && n_steps == 0);
+		polr_router_step_impl(m, mg, round, prefix, us, x.counts, k, (n_blocks ? n_blocks : 1u) * wpb, lane, true, &oc,
+		                      reset && n_steps == 0);
 		__builtin_amdgcn_wave_barrier();
 		// (all lanes read what lane 0 left in LDS)
 		round_no = polr_res_next_round(round_no);
@@ -452,11 +475,21 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 			break;
 		}
 		const volatile DevRound *vr = round;
+		if (n_blocks == 0) {
+			// not one worker workgroup got onto the device in 4 s: give up (reported like a lost worker)
+			__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, POLR_RES_DONE), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+			if (lane == 0 && host_words) {
+				host_words[2] = 1;
+			}
+			break;
+		}
 		const unsigned long long bw = (unsigned long long)(uint32_t)vr->begin |
-		                              ((unsigned long long)(((volatile uint32_t *)us)[0] & 0xFFFu) << 32) |
-		                              ((unsigned long long)(vr->path & 31u) << 44) |
-		                              ((unsigned long long)(vr->emit & 1u) << 49) |
-		                              ((unsigned long long)polr_res_tag(x.epoch, round_no) << 50);
+		                              ((unsigned long long)((((volatile uint32_t *)us)[0] >> 6) & 63u) << 32) |
+		                              ((unsigned long long)(vr->path & 31u) << 38) |
+		                              ((unsigned long long)(vr->emit & 1u) << 43) |
+		                              ((unsigned long long)(n_blocks & 0xFFFu) << 44) |
+		                              ((unsigned long long)polr_res_tag(x.epoch, round_no) << 56);
 		__hip_atomic_store(&x.sync->pub[lane].b, bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, (uint32_t)vr->count),
 		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -926,8 +926,7 @@ __device__ __forceinline__ void flush_counts(WaveCtx<W, K> &c, unsigned long lon
 // output chunk) across rounds; between rounds a workgroup sleeps on its barrier while its first thread polls.
 template <int W, int K>
 __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline *__restrict__ pipe,
-                                                            const ResidentExec *__restrict__ execs, uint32_t n_exec,
-                                                            DevOut out) {
+                                                               ResidentExec *execs, uint32_t n_exec, DevOut out) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	__shared__ __attribute__((aligned(16))) uint32_t router_lds[POLR_RES_ROUTER_DWORDS];
 	__shared__ unsigned long long bcast[2][2];
@@ -935,8 +934,6 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	const uint32_t wpb = blockDim.x >> 6;
 	const uint32_t e = blockIdx.x % n_exec;
 	const uint32_t b = blockIdx.x / n_exec;
-	const uint32_t n_wblocks = gridDim.x / n_exec - 1; // host: grid is a multiple of n_exec, >= 2 per executor
-	const uint32_t n_workers = n_wblocks * wpb;
 	const uint32_t k = uni(pipe->k);
 	ResidentExec x;
 	{
@@ -957,7 +954,8 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	if (b == 0) {
 		if (wave_in_block == 0) {
 			const uint32_t dyn_dwords = wpb * per_wave_dwords<W, K>();
-			polr_resident_router(x, k, n_workers, threadIdx.x & 63, router_lds, (uint64_t *)lds, dyn_dwords / 2);
+			polr_resident_router(x, k, &execs[e].registered, wpb, threadIdx.x & 63, router_lds, (uint64_t *)lds,
+			                     dyn_dwords / 2);
 		}
 		return;
 	}
@@ -988,8 +986,14 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	c.fill = 0;
 	c.overflow = false;
 	const StageDesc *stages = uniptr(pipe->stages);
-	// small rounds spread over the CUs: consecutive ranks sit in different workgroups
-	const uint32_t rank = wave_in_block * n_wblocks + (b - 1);
+	// register: the order in which worker workgroups start is their rank; the router deals a round only to
+	// the workgroups registered when it routes it
+	__shared__ uint32_t reg_rank_s;
+	if (threadIdx.x == 0) {
+		reg_rank_s = atomicAdd(&execs[e].registered, 1u);
+	}
+	__syncthreads();
+	const uint32_t reg_rank = reg_rank_s;
 	const uint32_t epoch12 = x.epoch & 0xFFFu;
 	uint32_t my_round = 0; // (thread 0 only)
 	const uint32_t copy = b % POLR_RES_COPIES;
@@ -1014,7 +1018,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 				const uint32_t tag = polr_res_tag(x.epoch, my_round);
 				while (true) {
 					bw = __hip_atomic_load(&x.sync->pub[copy].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if ((uint32_t)(bw >> 50) == tag) {
+					if ((uint32_t)(bw >> 56) == tag) {
 						break;
 					}
 					__builtin_amdgcn_s_sleep(1);
@@ -1039,11 +1043,14 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 			break;
 		}
 		const uint64_t rb = uni((uint32_t)bw);
-		const uint32_t us = uni((uint32_t)(bw >> 32) & 0xFFFu);
-		const uint32_t pidx = uni((uint32_t)(bw >> 44) & 31u);
-		const bool emit = uni((uint32_t)(bw >> 49) & 1u) != 0;
+		const uint32_t us = uni((uint32_t)(bw >> 32) & 63u) << 6;
+		const uint32_t pidx = uni((uint32_t)(bw >> 38) & 31u);
+		const bool emit = uni((uint32_t)(bw >> 43) & 1u) != 0;
+		const uint32_t n_blocks = uni((uint32_t)(bw >> 44) & 0xFFFu); // workgroups this round is dealt to
 		const uint32_t n_units = (count + us - 1) / us;
-		if (rank < n_units) {
+		// small rounds spread over the CUs: consecutive units go to different workgroups
+		const uint32_t first_unit = reg_rank + n_blocks * wave_in_block;
+		if (reg_rank < n_blocks && first_unit < n_units) {
 			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)pidx * POLR_KMAX);
 			uint32_t *dst = (uint32_t *)c.desc;
 			for (uint32_t i = c.lane; i < K * STAGE_DESC_DWORDS; i += 64) {
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 			c.emit = emit && !c.overflow;
 			c.wide_mask = stage_wide_mask<W, K>(src, c.k);
 			uint32_t my_units = 0;
-			for (uint32_t unit = rank; unit < n_units; unit += n_workers) {
+			for (uint32_t unit = first_unit; unit < n_units; unit += n_blocks * wpb) {
 				c.in_pos = rb + (uint64_t)unit * us;
 				c.in_end = c.in_pos + us;
 				if (c.in_end > rb + count) {
@@ -1286,7 +1293,9 @@ static hipError_t launch_res(dim3 grid, dim3 block, size_t lds, hipStream_t stre
 	if (e != hipSuccess) {
 		return e;
 	}
-	hipLaunchKernelGGL((polr_resident_kernel<W, POLR_K>), grid, block, lds, stream, pipe, execs, n_exec, out);
+	(void)hipGetLastError(); // (a stale error of an unrelated earlier call must not be blamed on this launch)
+	hipLaunchKernelGGL((polr_resident_kernel<W, POLR_K>), grid, block, lds, stream, pipe, (ResidentExec *)execs, n_exec,
+	                   out);
 	return hipGetLastError();
 }
 
@@ -1342,6 +1351,7 @@ static hipError_t launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t stream
 		}
 		lds_set = lds;
 	}
+	(void)hipGetLastError(); // (a stale error of an unrelated earlier call must not be blamed on this launch)
 	hipLaunchKernelGGL((polr_path_kernel<W, POLR_K>), grid, block, lds, stream, pipe, rounds, unit_prefix, n_rounds,
 	                   unit_sizes, out, counts, sr);
 	return hipGetLastError();
