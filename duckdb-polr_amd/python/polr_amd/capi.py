@@ -30,7 +30,7 @@ EXPORTS = [
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
-    "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks",
+    "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate",
 ]
 
 
@@ -58,6 +58,18 @@ class ScanFilter(C.Structure):
 
 
 CMP = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, ">": 3, "<=": 4, ">=": 5, "is null": 6, "is not null": 7}
+
+
+class AggSpec(C.Structure):
+    _fields_ = [("fn", C.c_uint32), ("src_join", C.c_int32), ("src_col", C.c_uint32)]
+
+
+class AggValue(C.Structure):
+    _fields_ = [("lo", C.c_int64), ("hi", C.c_int64), ("count", C.c_uint64), ("is_null", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
+AGG = {"count_star": 0, "count": 1, "sum": 2, "min": 3, "max": 4}
 
 
 class HtInfo(C.Structure):
@@ -135,6 +147,7 @@ def load():
     L.polr_pipeline_scan_filter.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.polr_pipeline_fetch_scan.argtypes = [vp, vp, vp]
     L.polr_mpx_use_scan_chunks.argtypes = [vp]
+    L.polr_out_aggregate.argtypes = [vp, vp, vp, u32, vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
@@ -393,6 +406,20 @@ class Output:
         n, _, _ = self.stats(stream)
         out = np.zeros((n, 1 + self.pipe.k), dtype=np.uint32)
         self.ctx.check(self.ctx.L.polr_out_fetch_ids(self.h, stream, out.ctypes.data, n))
+        return out
+
+    def aggregate(self, specs, stream=None):
+        """polr_out_aggregate: specs = [(fn, src_join, src_col)] with fn in AGG -> [python int or None]
+        (ungrouped COUNT(*) / COUNT / SUM / MIN / MAX over the output, reduced on the device)"""
+        n = len(specs)
+        arr = (AggSpec * n)()
+        for i, (fn, sj, sc) in enumerate(specs):
+            arr[i].fn, arr[i].src_join, arr[i].src_col = AGG[fn] if isinstance(fn, str) else fn, sj, sc
+        res = (AggValue * n)()
+        self.ctx.check(self.ctx.L.polr_out_aggregate(self.h, stream, arr, n, res))
+        out = []
+        for r in res:
+            out.append(None if r.is_null else (r.hi << 64) + (r.lo & 0xFFFFFFFFFFFFFFFF))
         return out
 
     def materialize(self, src_join, src_col, dtype, stream=None):

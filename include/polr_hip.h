@@ -206,6 +206,29 @@ int polr_out_fetch_ids(polr_out *o, void *stream, uint32_t *dst, uint64_t dst_ro
  * src_col of join src_join.  dst_data/dst_valid are host or device pointers (dst_flags). */
 int polr_out_materialize(polr_out *o, void *stream, int32_t src_join, uint32_t src_col, void *dst_data,
                          uint8_t *dst_valid, uint64_t dst_rows, uint32_t dst_flags);
+
+/* ---- sink side on the device -------------------------------------------
+ * PhysicalUngroupedAggregate over the pipeline's output (src/execution/operator/aggregate/
+ * physical_ungrouped_aggregate.cpp): COUNT(*), COUNT(x), SUM(x), MIN(x), MAX(x) over an integer column x of
+ * the probe table (src_join = -1) or of a build side, gathered by the output row ids and reduced on the
+ * device -- no column is materialised, only the results leave.  NULLs take no part; SUM is exact in 128 bits
+ * (DuckDB: SUM(INTEGER|BIGINT) -> HUGEINT, sum.cpp:113-144) and, like MIN / MAX, NULL over no rows; COUNT is
+ * never NULL.  The output object must have been filled by a materialising run (polr_probe_rounds / polr_mpx_run*
+ * with an `out`).  VARCHAR / unsigned 64-bit columns: POLR_E_UNSUPPORTED. */
+enum { POLR_AGG_COUNT_STAR = 0, POLR_AGG_COUNT = 1, POLR_AGG_SUM = 2, POLR_AGG_MIN = 3, POLR_AGG_MAX = 4 };
+typedef struct polr_agg_spec {
+	uint32_t fn;       /* POLR_AGG_* */
+	int32_t src_join;  /* -1 = probe-table column, j >= 0 = payload column of join j (ignored for COUNT(*)) */
+	uint32_t src_col;
+} polr_agg_spec;
+typedef struct polr_agg_value {
+	int64_t lo, hi;    /* the value as a two's complement 128-bit integer (hi:lo) */
+	uint64_t count;    /* rows that took part */
+	uint32_t is_null;
+	uint32_t pad;
+} polr_agg_value;
+int polr_out_aggregate(polr_out *o, void *stream, const polr_agg_spec *specs, uint32_t n_aggs,
+                       polr_agg_value *results);
 void polr_out_destroy(polr_out *o);
 
 /* ---------------------------------------------------------------------------------------------

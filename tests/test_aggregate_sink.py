@@ -1,0 +1,127 @@
+"""Sink side of the pipeline: ungrouped COUNT(*) / COUNT / SUM / MIN / MAX.
+
+tests/golden/aggregates.json holds the REFERENCE's answers (tests/golden/make_golden_agg.py: its own SQL
+with POLAR enabled) for every output column of the four parity scenarios, NULLs included.
+CPU part: the oracle's pipeline + column materialisation reproduce those answers (exact Python integers).
+GPU part (-m gpu): polr_out_aggregate over the device pipeline's row-id output gives the same numbers,
+for every routing strategy's output, plus 128-bit / negative / all-NULL / empty cases against Python ints."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import common
+from common import orc, workloads
+
+GOLD = json.load(open(os.path.join(common.GOLDEN, "aggregates.json")))
+SCENARIOS = {
+    "star_skew": lambda: workloads.star_skew(),
+    "star_skew_nulls": lambda: workloads.star_skew(n_fact=60_000, with_nulls=True),
+    "chain_dep": lambda: workloads.chain_dep(),
+    "fanout": lambda: workloads.fanout(),
+}
+
+
+def exact(data, valid):
+    """python-int aggregates of a materialised column (NULLs take no part)"""
+    vals = [int(v) for v, ok in zip(data.tolist(), (valid.tolist() if valid is not None else [1] * len(data))) if ok]
+    return {"count": len(vals), "sum": sum(vals) if vals else None, "min": min(vals) if vals else None,
+            "max": max(vals) if vals else None}
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_oracle_reproduces_reference_aggregates(name):
+    wl = SCENARIOS[name]()
+    g = GOLD[name]
+    pcols, pvalid, joins = common.oracle_joins(wl)
+    k = len(joins)
+    res = orc.run_pipeline(pcols, joins, [list(range(k))], routing="default_path", probe_valid=pvalid)
+    rows = res["out_rows"]
+    assert len(rows) == g["count_star"]
+    for (src_join, arr, valid), cname in zip(common.output_columns(wl), g["out_cols"]):
+        data, v = orc.materialize_column(rows, k, src_join, arr, valid)
+        assert exact(data, v) == g["columns"][cname], cname
+
+
+# ---- GPU -------------------------------------------------------------------------------------------
+def _col_index(wl, src_join, arr):
+    src = wl["probe"]["cols"] if src_join < 0 else wl["joins"][src_join]["payload"]
+    return [i for i, a in enumerate(src.values()) if a is arr][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SCENARIOS))
+@pytest.mark.parametrize("routing", ["adaptive_reinit", "default_path", "dynamic"])
+def test_device_aggregates_match_reference(gpu_ctx, name, routing):
+    from polr_amd import capi
+    from test_gpu_probe import gpu_pipeline, scenario_paths
+    wl = SCENARIOS[name]()
+    g = GOLD[name]
+    paths = scenario_paths(wl, "each_last_once")
+    pipe, joins, n = gpu_pipeline(gpu_ctx, wl, paths)
+    out = capi.Output(pipe, 1024, 8192)
+    mpx = capi.DeviceMultiplexer(pipe, routing)
+    mpx.run_resident(0, (n + 1023) // 1024, out=out)
+    mpx.finish()
+    specs, names = [("count_star", -1, 0)], []
+    for (src_join, arr, valid), cname in zip(common.output_columns(wl), g["out_cols"]):
+        ci = _col_index(wl, src_join, arr)
+        for fn in ("count", "sum", "min", "max"):
+            specs.append((fn, src_join, ci))
+        names.append(cname)
+    got = []
+    for i in range(0, len(specs), 8):  # at most 8 aggregates per call
+        got += out.aggregate(specs[i:i + 8])
+    assert got[0] == g["count_star"]
+    for i, cname in enumerate(names):
+        cnt, s, mn, mx = got[1 + 4 * i:5 + 4 * i]
+        assert {"count": cnt, "sum": s, "min": mn, "max": mx} == g["columns"][cname], cname
+    mpx.close()
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_device_aggregates_wide_values_and_nulls(gpu_ctx):
+    """sums beyond 64 bits, negative values, every integer width, all-NULL and empty outputs"""
+    from polr_amd import capi
+    rng = np.random.default_rng(5)
+    n = 300_000
+    keys = np.arange(1000, dtype=np.int32)
+    big = rng.integers(-2 ** 62, 2 ** 62, size=1000, dtype=np.int64)  # build payload: sums overflow int64
+    small = rng.integers(-100, 100, size=1000).astype(np.int8)
+    u16 = rng.integers(0, 65535, size=1000).astype(np.uint16)
+    allnull = np.zeros(1000, dtype=np.int32)
+    pv = [None, None, None, np.zeros(1000, dtype=np.uint8)]
+    ht = capi.HashTable.from_columns(gpu_ctx, [keys], [big, small, u16, allnull], payload_valid=pv)
+    ht.finalize_hash()
+    fk = rng.integers(0, 1200, size=n).astype(np.int32)  # ~1/6 without a partner
+    pcol_valid = (rng.random(n) > 0.1).astype(np.uint8)
+    val = rng.integers(-2 ** 31, 2 ** 31 - 1, size=n).astype(np.int32)
+    pipe = capi.Pipeline(gpu_ctx, [fk, val], n, [(ht, [(-1, 0)])], [[0]], probe_valid=[None, pcol_valid])
+    out = capi.Output(pipe, 1024, 8192)  # (every emitting wave owns a partially filled chunk)
+    pipe.probe_rounds([(0, n, 0, 1)], out=out)
+    ids = out.fetch_ids()
+    prow, brow = ids[:, 0].astype(np.int64), ids[:, 1].astype(np.int64)
+    want = [len(ids)]
+    specs = [("count_star", -1, 0)]
+    for src_join, ci, data, valid in [(-1, 1, val[prow], pcol_valid[prow]), (0, 0, big[brow], None),
+                                      (0, 1, small[brow], None), (0, 2, u16[brow], None),
+                                      (0, 3, allnull[brow], np.zeros(len(brow), dtype=np.uint8))]:
+        e = exact(data, valid)
+        for fn in ("count", "sum", "min", "max"):
+            specs.append((fn, src_join, ci))
+            want.append(e[fn])
+    got = []
+    for i in range(0, len(specs), 8):
+        got += out.aggregate(specs[i:i + 8])
+    assert got == want
+    assert abs(want[6]) > 2 ** 63  # the 128-bit path was exercised
+    # empty output: COUNT = 0, everything else NULL
+    out.reset()
+    gpu_ctx.sync()
+    assert out.aggregate([("count_star", -1, 0), ("sum", -1, 1), ("min", 0, 0), ("count", 0, 1)]) == [0, None, None, 0]
+    with pytest.raises(capi.PolrError):
+        out.aggregate([("sum", 0, 9)])
+    pipe.close()
+    ht.close()
