@@ -169,6 +169,10 @@ def main():
     ap.add_argument("--host-filter", action="store_true",
                     help="upload the host-computed selection instead of running the pushed-down filter of the source "
                          "scan on the device (polr_pipeline_scan_filter); either way it happens before the clock starts")
+    ap.add_argument("--sync-every-step", action="store_true",
+                    help="read the statistics of every pass back before enqueueing the next one (default: the K "
+                         "passes of the timed region are enqueued back to back on the stream, one synchronisation at "
+                         "the end -- every pass still resets, routes, probes and closes itself on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -300,11 +304,14 @@ def main():
     mpxs = [x[0] for x in execs]
     ranges = [(x[2], x[3]) for x in execs]
 
-    def step():
+    pipelined = args.launch == "resident" and not args.sync_every_step
+
+    def step(fetch=True):
         if args.launch == "resident":
             # fresh multiplexer states, the whole pass and the closing FinalizePathRun: one launch
             capi.run_resident(mpxs, ranges, reset=True, finish=True)
-            results[:] = capi.finish_many(mpxs)
+            if fetch:
+                results[:] = capi.finish_many(mpxs)
             return results
         for m in mpxs:
             m.reset()
@@ -335,8 +342,8 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(fetch=not pipelined or i == args.steps - 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -352,8 +359,8 @@ def main():
             m.enable_timing(True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            step(fetch=not pipelined or i == args.steps - 1)
         torch.cuda.synchronize()
         dt_events = time.perf_counter() - t1
         for m, _s, _a, _b in execs:
@@ -413,7 +420,8 @@ def main():
                                     joins_info[1]["n_rows"]) if args.workload == "job_light_01" else args.workload,
                        "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
-                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch},
+                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch,
+                       "passes_in_flight": "back to back on one stream" if pipelined else "synchronised per pass"},
             "total_intermediates": int(st["num_intermediates"]),
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],

@@ -509,11 +509,9 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 	}
 	const uint32_t n_blocks = per_exec * n;
 	for (uint32_t i = 0; i < n; i++) {
+		// (work still queued on `st` needs no host synchronisation: everything a resident run touches is
+		// ordered by the stream -- consecutive passes can be enqueued back to back)
 		HIPCHK(ctx, adopt_stream(ms[i], st));
-		if (ms[i]->pending_sync) {
-			HIPCHK(ctx, hipStreamSynchronize(st));
-			ms[i]->pending_sync = false;
-		}
 	}
 	if (m0->execs_cap < n) {
 		if (m0->execs_dev) {
