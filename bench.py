@@ -166,6 +166,10 @@ def main():
                     help="resident: the whole pass is ONE launch (device-resident routing loop, "
                          "polr_mpx_run_resident); rounds: one self-routing launch per routing round "
                          "(polr_mpx_run / _run_many)")
+    ap.add_argument("--reference-tables", action="store_true",
+                    help="index the build sides exactly as the reference's planner would (perfect table only below its "
+                         "1 M-value cap); default: polr_ht_finalize_auto -- dense unique integer keys of any range "
+                         "become 1-bit-per-value perfect tables that stay in L2")
     ap.add_argument("--host-filter", action="store_true",
                     help="upload the host-computed selection instead of running the pushed-down filter of the source "
                          "scan on the device (polr_pipeline_scan_filter); either way it happens before the clock starts")
@@ -222,7 +226,7 @@ def main():
                            "perfect": False})
     t_build0 = time.time()
     if rank == 0:
-        joins = capi.build_joins(ctx, wl0)
+        joins = capi.build_joins(ctx, wl0, auto=not args.reference_tables)
     bcast_bytes = 0
     if world > 1:
         new_joins = []
@@ -421,6 +425,7 @@ def main():
                        "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
                        "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch,
+                       "build_tables": ["perfect" if ji["perfect"] else "hash" for ji in joins_info],
                        "passes_in_flight": "back to back on one stream" if pipelined else "synchronised per pass"},
             "total_intermediates": int(st["num_intermediates"]),
             "routing_rounds": int(st["num_rounds"]),

@@ -546,6 +546,31 @@ int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, 
 	return rc;
 }
 
+int polr_ht_finalize_auto(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream, uint32_t *kind_out) {
+	if (!ht) {
+		return POLR_E_INVALID;
+	}
+	int rc = POLR_E_DUPLICATE;
+	const bool is_signed = ht->key_signed != 0;
+	const bool ordered = is_signed ? max_value >= min_value : (uint64_t)max_value >= (uint64_t)min_value;
+	if (ht->kind == KIND_NONE && ht->n_keys == 1 && ordered && ht->n_rows_in > 0) {
+		const uint64_t range = is_signed ? (uint64_t)(max_value - min_value) : (uint64_t)max_value - (uint64_t)min_value;
+		if (range < (1ull << 31) && range / POLR_DENSE_FACTOR <= ht->n_rows_in) {
+			rc = polr_ht_finalize_perfect(ht, min_value, max_value, stream);
+			if (rc != POLR_OK && rc != POLR_E_DUPLICATE) {
+				return rc;
+			}
+		}
+	}
+	if (rc == POLR_E_DUPLICATE) {
+		rc = polr_ht_finalize_hash(ht, stream);
+	}
+	if (!rc && kind_out) {
+		*kind_out = ht->kind;
+	}
+	return rc;
+}
+
 int polr_pht_upload(polr_ctx *ctx, uint32_t key_width, uint32_t key_flags, int64_t min_value, int64_t max_value,
                     const uint8_t *bitmap, const polr_col *payload, uint32_t n_payload, polr_ht **out) {
 	if (!ctx || !out || !bitmap) {

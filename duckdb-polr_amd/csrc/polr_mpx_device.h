@@ -347,10 +347,15 @@ __device__ __forceinline__ void polr_write_stats(const DevMpx *m, DevMpx *mg, po
 		stats->input_tuple_count_per_path[i] = i < core.path_count ? core.input_tuple_count_per_path[i] : 0;
 		stats->path_resistances[i] = i < core.path_count ? core.path_resistances[i] : 0;
 	}
+	// (only the cells of real join orders can be non-zero: one dependent round trip instead of four)
+	const uint32_t live = core.path_count * POLR_MAX_JOINS;
 	for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
-		stats->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = __hip_atomic_load(
-		    (unsigned long long *)&mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS], __ATOMIC_RELAXED,
-		    __HIP_MEMORY_SCOPE_AGENT);
+		unsigned long long v = 0;
+		if (i < live) {
+			v = __hip_atomic_load((unsigned long long *)&mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS],
+			                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		stats->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = v;
 	}
 }
 

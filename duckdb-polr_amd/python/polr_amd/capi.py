@@ -30,7 +30,7 @@ EXPORTS = [
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
-    "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate",
+    "polr_ht_finalize_auto", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate",
 ]
 
 
@@ -144,6 +144,7 @@ def load():
     L.polr_mpx_reset.argtypes = [vp, vp]
     L.polr_mpx_run_many.argtypes = [vp, vp, vp, vp, u32, vp]
     L.polr_mpx_finish_many.argtypes = [vp, u32, vp]
+    L.polr_ht_finalize_auto.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
     L.polr_pipeline_scan_filter.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.polr_pipeline_fetch_scan.argtypes = [vp, vp, vp]
     L.polr_mpx_use_scan_chunks.argtypes = [vp]
@@ -263,6 +264,12 @@ class HashTable:
             return False
         self.ctx.check(rc)
         return True
+
+    def finalize_auto(self, min_value, max_value, stream=None):
+        """polr_ht_finalize_auto: perfect table for a dense unique integer key, hash table otherwise -> kind"""
+        kind = C.c_uint32()
+        self.ctx.check(self.ctx.L.polr_ht_finalize_auto(self.h, int(min_value), int(max_value), stream, C.byref(kind)))
+        return kind.value
 
     def info(self):
         i = HtInfo()
@@ -555,16 +562,24 @@ def finish_many(mpxs):
     return [_stats_dict(stats[i], mpxs[i].pipe.n_paths, mpxs[i].pipe.k) for i in range(n)]
 
 
-def build_joins(ctx, wl):
-    """upload + finalize the build sides of a workload dict the way the reference's planner would:
-    perfect table where the plan allows it and the build has no duplicate, hash table otherwise."""
+def build_joins(ctx, wl, auto=False):
+    """upload + finalize the build sides of a workload dict.  auto=False: the way the reference's planner would
+    (perfect table where the plan allows it and the build has no duplicate, hash table otherwise);
+    auto=True: polr_ht_finalize_auto with the key column's min/max statistics (dense unique keys of any range
+    become perfect tables)."""
     joins = []
     for j in wl["joins"]:
         pv = [j.get("payload_valid", {}).get(n) for n in j["payload"].keys()]
         ht = HashTable.from_columns(ctx, j["keys"], list(j["payload"].values()), key_valid=j.get("key_valid"),
                                     payload_valid=pv)
         done = False
-        if j.get("perfect") is not None:
+        if auto and len(j["keys"]) == 1 and j["keys"][0].dtype.kind in "iu" and len(j["keys"][0]):
+            kv = j.get("key_valid")
+            kk = j["keys"][0] if not kv or kv[0] is None else j["keys"][0][kv[0].astype(bool)]
+            if len(kk):
+                ht.finalize_auto(int(kk.min()), int(kk.max()))
+                done = True
+        if not done and j.get("perfect") is not None:
             done = ht.finalize_perfect(*j["perfect"])
         if not done:
             ht.finalize_hash()

@@ -111,6 +111,15 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream);
  * keys outside [min,max] are skipped; a duplicate inside the range returns POLR_E_DUPLICATE and
  * leaves the handle un-finalized so the caller can polr_ht_finalize_hash it instead. */
 int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream);
+/* Let the device pick the index: a single integer key whose value range [min,max] (the build column's
+ * statistics, as PerfectHashJoinStats carries them: build_min / build_max) is at most POLR_DENSE_FACTOR x
+ * the build rows becomes a perfect table (1 bit per key value: 3 M dense keys = 375 KB, L2-resident, where a
+ * bucket table would cost one random 64-B HBM line per probe) -- the reference's own perfect-hash idea without
+ * its 1 M-value cap (perfect_hash_join_executor.cpp:25-50), which was sized for CPU caches; anything else,
+ * and a range with a duplicate key, becomes a hash table.  Match sets are identical either way; *kind_out
+ * (may be NULL) tells which build-id convention applies (see polr_ht_get_info). */
+#define POLR_DENSE_FACTOR 8
+int polr_ht_finalize_auto(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream, uint32_t *kind_out);
 /* Upload a perfect table the reference already built (PerfectHashJoinExecutor members
  * perfect_hash_table / bitmap_build_idx, perfect_hash_join_executor.hpp): bitmap has range+1
  * bools, each payload column has range+1 cells. */

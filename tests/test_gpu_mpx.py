@@ -180,3 +180,36 @@ def test_executors_match_single_executor_runs(gpu_ctx, launch, n_exec):
         assert np.array_equal(_sorted_rows(out.fetch_ids()), want_rows)
     for m in mpxs:
         m.close()
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_auto_indexed_tables_match_reference(gpu_ctx, name):
+    """polr_ht_finalize_auto (dense unique integer keys of ANY range become perfect tables, beyond the
+    reference's 1 M-value cap): same routing trace, same totals, same result digest as the reference"""
+    gold = common.load_golden(name)
+    g = gold["routing"]["each_last_once/adaptive_reinit/nocache"]
+    wl = SCENARIOS[name]()
+    paths = scenario_paths(wl, "each_last_once")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    kinds = [j[0].info()["kind"] for j in joins]
+    probe = wl["probe"]
+    names = list(probe["cols"].keys())
+    pv = [probe.get("valid", {}).get(n_) for n_ in names]
+    n = len(probe["cols"][names[0]])
+    pipe = capi.Pipeline(gpu_ctx, list(probe["cols"].values()), n, joins, paths, probe_valid=pv)
+    mpx = capi.DeviceMultiplexer(pipe, "adaptive_reinit", chunk_size=1024)
+    out = capi.Output(pipe, 1024, 8192)
+    mpx.run_resident(0, (n + 1023) // 1024, out=out)
+    st = mpx.finish()
+    _, tuples, inter = mpx.fetch_log()
+    assert list(inter) == g["rounds"], kinds
+    assert st["num_intermediates"] == g["intms"]
+    assert st["input_tuple_count_per_path"] == g["tuple_counts"]
+    cols = []
+    for src_join, arr, valid in common.output_columns(wl):
+        src = wl["probe"]["cols"] if src_join < 0 else wl["joins"][src_join]["payload"]
+        col_idx = [i for i, a in enumerate(src.values()) if a is arr][0]
+        cols.append(out.materialize(src_join, col_idx, arr.dtype))
+    assert common.rows_digest_from_columns(cols) == (g["rows_sha256"], g["n_rows"])
+    mpx.close()
+    pipe.close()
