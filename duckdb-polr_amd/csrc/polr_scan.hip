@@ -111,7 +111,7 @@ __device__ __forceinline__ bool row_passes(const DevFilterSet &fs, uint64_t row)
 }
 
 // one wave per vector (grid-stride); counts[v] = survivors of vector v, packed with its non-empty flag
-__global__ __launch_bounds__(256) void polr_scan_count_kernel(DevFilterSet fs, uint64_t n_rows, uint32_t V,
+__global__ __launch_bounds__(256) void polr_tscan_count_kernel(DevFilterSet fs, uint64_t n_rows, uint32_t V,
                                                               uint64_t n_vec, unsigned long long *__restrict__ packed) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void polr_scan_count_kernel(DevFilterSet fs, u
 }
 
 // block sums of 1024 packed entries each
-__global__ __launch_bounds__(1024) void polr_scan_block_sums_kernel(const unsigned long long *__restrict__ packed,
+__global__ __launch_bounds__(1024) void polr_tscan_block_sums_kernel(const unsigned long long *__restrict__ packed,
                                                                     uint64_t n_vec,
                                                                     unsigned long long *__restrict__ sums) {
 	__shared__ unsigned long long warp_sums[16];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void polr_scan_block_sums_kernel(const unsign
 }
 
 // one block: exclusive scan of the block sums in place; total -> totals[0] (tuples), totals[1] (chunks)
-__global__ __launch_bounds__(1024) void polr_scan_sums_kernel(unsigned long long *__restrict__ sums, uint64_t n_blocks,
+__global__ __launch_bounds__(1024) void polr_tscan_sums_kernel(unsigned long long *__restrict__ sums, uint64_t n_blocks,
                                                               unsigned long long *__restrict__ totals) {
 	__shared__ unsigned long long warp_tot[16];
 	__shared__ unsigned long long carry_s;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void polr_scan_sums_kernel(unsigned long long
 }
 
 // exclusive prefix of every vector = block base + scan inside the block of 1024; in place
-__global__ __launch_bounds__(1024) void polr_scan_apply_kernel(unsigned long long *__restrict__ packed, uint64_t n_vec,
+__global__ __launch_bounds__(1024) void polr_tscan_apply_kernel(unsigned long long *__restrict__ packed, uint64_t n_vec,
                                                                const unsigned long long *__restrict__ sums) {
 	__shared__ unsigned long long warp_tot[16];
 	const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(1024) void polr_scan_apply_kernel(unsigned long lon
 }
 
 // one wave per vector: ascending row ids of the survivors, chunk boundary of every non-empty vector
-__global__ __launch_bounds__(256) void polr_scan_write_kernel(DevFilterSet fs, uint64_t n_rows, uint32_t V,
+__global__ __launch_bounds__(256) void polr_tscan_write_kernel(DevFilterSet fs, uint64_t n_rows, uint32_t V,
                                                               uint64_t n_vec,
                                                               const unsigned long long *__restrict__ prefix,
                                                               uint32_t *__restrict__ sel,
@@ -322,16 +322,16 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 		const uint32_t waves_per_block = 4;
 		const uint32_t grid = (uint32_t)std::min<uint64_t>((n_vec + waves_per_block - 1) / waves_per_block,
 		                                                   (uint64_t)ctx->n_cus * 8);
-		hipLaunchKernelGGL(polr_scan_count_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec, packed);
-		hipLaunchKernelGGL(polr_scan_block_sums_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
-		hipLaunchKernelGGL(polr_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, n_blocks, totals);
-		hipLaunchKernelGGL(polr_scan_apply_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
+		hipLaunchKernelGGL(polr_tscan_count_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec, packed);
+		hipLaunchKernelGGL(polr_tscan_block_sums_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
+		hipLaunchKernelGGL(polr_tscan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, n_blocks, totals);
+		hipLaunchKernelGGL(polr_tscan_apply_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
 		e = hipMemcpyAsync(h_tot, totals, 16, hipMemcpyDeviceToHost, st);
 		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
 		e = e == hipSuccess ? hipMalloc((void **)&sel, std::max<uint64_t>(h_tot[0], 1) * 4) : e;
 		e = e == hipSuccess ? hipMalloc((void **)&offs, (h_tot[1] + 1) * 8) : e;
 		if (e == hipSuccess) {
-			hipLaunchKernelGGL(polr_scan_write_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec,
+			hipLaunchKernelGGL(polr_tscan_write_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec,
 			                   packed, sel, offs, h_tot[0], h_tot[1]);
 			e = hipStreamSynchronize(st);
 		}
