@@ -173,6 +173,10 @@ def main():
     ap.add_argument("--host-filter", action="store_true",
                     help="upload the host-computed selection instead of running the pushed-down filter of the source "
                          "scan on the device (polr_pipeline_scan_filter); either way it happens before the clock starts")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="P > 1: P passes in flight -- P sets of executors on P streams, each sized for 1/P of the "
+                         "device (POLR_RUN_SHARE), passes enqueued round-robin; the exploration rounds of one pass "
+                         "overlap the table-sized round of another (inter-query parallelism; per-pass latency rises)")
     ap.add_argument("--sync-every-step", action="store_true",
                     help="read the statistics of every pass back before enqueueing the next one (default: the K "
                          "passes of the timed region are enqueued back to back on the stream, one synchronisation at "
@@ -295,27 +299,39 @@ def main():
         offs = chunk_offsets_for(sel, n_rows, V)
         n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
     E = max(1, min(args.executors, n_chunks))
-    execs = []
-    for e in range(E):
-        m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
-                                   init_tuple_count=args.init_tuple_count, log_rounds=False)
-        if device_scan:
-            m.use_scan_chunks()
-        elif offs is not None:
-            m.set_chunk_offsets(offs)
-        execs.append((m, None, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
+    P = max(1, args.streams) if args.launch == "resident" and not args.sync_every_step else 1
+    sets = []
+    for _p in range(P):
+        execs = []
+        for e in range(E):
+            m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
+                                       init_tuple_count=args.init_tuple_count, log_rounds=False)
+            if device_scan:
+                m.use_scan_chunks()
+            elif offs is not None:
+                m.set_chunk_offsets(offs)
+            execs.append((m, None, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
+        sets.append(execs)
+    execs = sets[0]
     results = [None] * E
     mpxs = [x[0] for x in execs]
     ranges = [(x[2], x[3]) for x in execs]
+    all_mpxs = [x[0] for ex in sets for x in ex]
+    step_no = [0]
 
     pipelined = args.launch == "resident" and not args.sync_every_step
 
     def step(fetch=True):
         if args.launch == "resident":
             # fresh multiplexer states, the whole pass and the closing FinalizePathRun: one launch
-            capi.run_resident(mpxs, ranges, reset=True, finish=True)
+            cur = [x[0] for x in sets[step_no[0] % P]]
+            step_no[0] += 1
+            capi.run_resident(cur, ranges, reset=True, finish=True, share=P)
             if fetch:
-                results[:] = capi.finish_many(mpxs)
+                for ex in sets:  # (settles every stream; the statistics reported are the last pass's)
+                    got = capi.finish_many([x[0] for x in ex])
+                    if ex[0][0] is cur[0]:
+                        results[:] = got
             return results
         for m in mpxs:
             m.reset()
@@ -358,7 +374,7 @@ def main():
     # host time per launch, which is why they are kept out of the region `value` is computed from
     kernel_ms, launches, dt_events = 0.0, 0, None
     if not args.no_kernel_events:
-        for m, _s, _a, _b in execs:
+        for m in all_mpxs:
             m.kernel_time()
             m.enable_timing(True)
         torch.cuda.synchronize()
@@ -367,7 +383,7 @@ def main():
             step(fetch=not pipelined or i == args.steps - 1)
         torch.cuda.synchronize()
         dt_events = time.perf_counter() - t1
-        for m, _s, _a, _b in execs:
+        for m in all_mpxs:
             ms_e, n_e = m.kernel_time()
             kernel_ms += ms_e
             launches += n_e
@@ -426,7 +442,8 @@ def main():
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
                        "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch,
                        "build_tables": ["perfect" if ji["perfect"] else "hash" for ji in joins_info],
-                       "passes_in_flight": "back to back on one stream" if pipelined else "synchronised per pass"},
+                       "passes_in_flight": ("%d streams, 1/%d of the device each" % (P, P)) if P > 1 else
+                       ("back to back on one stream" if pipelined else "synchronised per pass")},
             "total_intermediates": int(st["num_intermediates"]),
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],
@@ -438,7 +455,7 @@ def main():
         print(json.dumps(line))
     # release the device objects while the runtime (and a profiler attached to it) is still alive: nothing is
     # left for interpreter shutdown to destroy in an arbitrary order
-    for m in mpxs:
+    for m in all_mpxs:
         m.close()
     pipe.close()
     for ht, _ in joins:

@@ -502,7 +502,11 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 	}
 	occ = std::min(occ, 8);
 	// grid: a multiple of n, at least router + one worker workgroup per executor, never more than is co-resident
-	const uint32_t capacity = (uint32_t)ctx->n_cus * (uint32_t)occ;
+	const uint32_t share = std::max<uint32_t>((flags >> 8) & 0xFFu, 1u);
+	if (share > 16) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "device share 1/%u: at most 16 resident runs side by side", share);
+	}
+	const uint32_t capacity = (uint32_t)ctx->n_cus * (uint32_t)occ / share;
 	uint32_t per_exec = capacity / n;
 	if (per_exec < 2) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "%u executors do not fit on the device at once", n);

@@ -541,7 +541,7 @@ def _stats_dict(st, P, k):
 RUN_RESET, RUN_FINISH = 1, 2
 
 
-def run_resident(mpxs, ranges, out=None, reset=False, finish=False):
+def run_resident(mpxs, ranges, out=None, reset=False, finish=False, share=1):
     """polr_mpx_run_resident: the same run as ONE launch (device-resident routing loop);
     reset / finish fold polr_mpx_reset / the closing FinalizePathRun into the same launch"""
     ctx = mpxs[0].ctx
@@ -550,7 +550,7 @@ def run_resident(mpxs, ranges, out=None, reset=False, finish=False):
     b = np.ascontiguousarray([r[0] for r in ranges], dtype=np.uint64)
     e = np.ascontiguousarray([r[1] for r in ranges], dtype=np.uint64)
     ctx.check(ctx.L.polr_mpx_run_resident(hs, None, b.ctypes.data, e.ctypes.data, n, out.h if out else None,
-                                          (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0)))
+                                          (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) | ((share & 0xFF) << 8 if share > 1 else 0)))
 
 
 def finish_many(mpxs):

@@ -315,6 +315,10 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
  * POLR_E_UNSUPPORTED: more than 64 executors / more executors than fit on the device at once. */
 #define POLR_RUN_RESET 1u
 #define POLR_RUN_FINISH 2u
+/* POLR_RUN_SHARE(d): size the grid for 1/d of the device (d = 2..16), so that d resident runs on d streams are
+ * co-resident and their rounds overlap (the small exploration rounds of one pass run beside the table-sized
+ * round of another) */
+#define POLR_RUN_SHARE(d) (((uint32_t)(d) & 0xFFu) << 8)
 int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                           uint32_t n, polr_out *out, uint32_t flags);
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
