@@ -1239,6 +1239,7 @@ int polr_out_create(polr_pipeline *p, uint32_t chunk_capacity, uint64_t max_chun
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_out *o = new polr_out();
 	o->pipe = p;
+	o->ctx = p->ctx;
 	memset(&o->dev, 0, sizeof(o->dev));
 	o->dev.chunk_capacity = chunk_capacity;
 	o->dev.max_chunks = (uint32_t)max_chunks;
@@ -1431,7 +1432,7 @@ void polr_out_destroy(polr_out *o) {
 	if (!o) {
 		return;
 	}
-	hipSetDevice(o->pipe->ctx->device);
+	hipSetDevice(o->ctx->device);
 	if (o->dev.ids) {
 		hipFree(o->dev.ids);
 	}

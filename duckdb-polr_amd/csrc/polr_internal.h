@@ -85,6 +85,7 @@ struct polr_pipeline {
 
 struct polr_out {
 	polr_pipeline *pipe = nullptr;
+	polr_ctx *ctx = nullptr; // (kept so that destroying the object never has to go through the pipeline)
 	DevOut dev;
 	uint64_t *chunk_base = nullptr; // [max_chunks] exclusive prefix, refreshed by stats
 	uint64_t *total_dev = nullptr;

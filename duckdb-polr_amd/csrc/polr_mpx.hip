@@ -24,6 +24,7 @@
 
 struct polr_mpx {
 	polr_pipeline *pipe = nullptr;
+	polr_ctx *ctx = nullptr; // (kept so that destroying the object never has to go through the pipeline)
 	polr_mpx_config cfg;
 	DevMpx *dev = nullptr;
 	DevRound *round_dev = nullptr;
@@ -194,6 +195,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_mpx *m = new polr_mpx();
 	m->pipe = p;
+	m->ctx = p->ctx;
 	m->cfg = *cfg;
 	m->n_chunks = (p->n_tuples + cfg->chunk_size - 1) / cfg->chunk_size;
 	const uint64_t max_log = cfg->log_rounds ? std::max<uint64_t>(cfg->max_log_rounds, 1) : 1;
@@ -749,7 +751,7 @@ void polr_mpx_destroy(polr_mpx *m) {
 	if (!m) {
 		return;
 	}
-	hipSetDevice(m->pipe->ctx->device);
+	hipSetDevice(m->ctx->device);
 	if (m->dev) {
 		hipFree(m->dev);
 	}

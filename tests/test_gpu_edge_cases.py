@@ -47,6 +47,28 @@ def run_both(ctx, probe_cols, joins_spec, paths, probe_valid=None, emit=True):
             want = ref["out_rows"]
             assert np.array_equal(rows[np.lexsort(rows.T[::-1])], want[np.lexsort(want.T[::-1])]), "path %d" % p
         results.append(ref["num_output_rows"])
+        # the same join order through the RESIDENT kernel (its own compiled instantiations): DEFAULT_PATH always
+        # takes path 0, so a pipeline whose path 0 is this order runs it over every chunk
+        if n:
+            rpipe = capi.Pipeline(ctx, probe_cols, n, gjoins, [paths[p]] + [q for i, q in enumerate(paths) if i != p],
+                                  probe_valid=probe_valid)
+            mpx = capi.DeviceMultiplexer(rpipe, "default_path", chunk_size=1024)
+            rout = capi.Output(rpipe, 1024, 8192) if emit else None
+            capi.run_resident([mpx], [(0, (n + 1023) // 1024)], out=rout, reset=True, finish=True)
+            st = mpx.finish()
+            assert st["num_intermediates"] == ref["num_intermediates"], "resident, path %d" % p
+            if emit:
+                rids = rout.fetch_ids()
+                rrows = rids.copy()
+                for x, oj in enumerate(ojoins):
+                    if oj.ht.pht:
+                        rrows[:, 1 + x] = oj.ht.pht_orig_rows()[rids[:, 1 + x]]
+                assert np.array_equal(rrows[np.lexsort(rrows.T[::-1])], want[np.lexsort(want.T[::-1])]), \
+                    "resident, path %d" % p
+            mpx.close()
+            if rout is not None:
+                rout.close()
+            rpipe.close()
     assert len(set(results)) == 1  # every join order yields the same number of rows
     return results[0]
 
