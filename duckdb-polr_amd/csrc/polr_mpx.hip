@@ -206,7 +206,8 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	e = e == hipSuccess ? hipMalloc((void **)&m->ticket_dev, 64) : e;
 	e = e == hipSuccess ? hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) : e;
 	e = e == hipSuccess ? hipMemset(m->ticket_dev, 0, 64) : e;
-	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_NSHARD * POLR_KMAX * 8) : e;
+	// two counter banks (a resident run keeps up to two rounds in flight; everything else uses the first)
+	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, 2 * POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_inter, max_log * 8) : e;
@@ -215,7 +216,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 		memset(m->done_host, 0, 64);
 		e = hipHostGetDevicePointer((void **)&m->progress_dev, m->done_host, 0);
 	}
-	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, 2 * POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->sync_dev, sizeof(ResidentSync)) : e;
 	e = e == hipSuccess ? hipHostMalloc((void **)&m->stats_host, sizeof(polr_mpx_stats), hipHostMallocMapped) : e;
 	e = e == hipSuccess ? hipHostGetDevicePointer((void **)&m->stats_host_dev, m->stats_host, 0) : e;
@@ -603,7 +604,7 @@ int polr_mpx_reset(polr_mpx *m, void *stream) {
 		m->pending_sync = false;
 	}
 	m->stats_in_host = false;
-	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_NSHARD * POLR_KMAX * 8, st));
+	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, 2 * POLR_NSHARD * POLR_KMAX * 8, st));
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
 	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask,
 	                   m->progress_dev, ((volatile uint32_t *)m->done_host)[0]);

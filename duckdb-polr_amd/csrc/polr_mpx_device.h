@@ -126,54 +126,69 @@ __device__ __forceinline__ void polr_router_step(DevMpx *mg, DevRound *round, ui
 	}
 }
 
+__device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, uint64_t *unit_prefix,
+                                                  uint32_t *unit_size_out, uint32_t resident_waves,
+                                                  const OffsCache *oc);
+
+// Absorb a counter bank: what RunPath feeds AddNumIntermediates (polar_pipeline_executor.cpp:486-487).  One
+// wave: lanes 0..31 sum the shards of counter j, lanes 32..63 those of j+1, a shuffle tree adds the shards.
+// Returns the sum of all k counters in lane 0 (0 elsewhere, and 0 when `discard`).
 // m: the state to work on (LDS copy or HBM), mg: the HBM object (for stage_out)
+__device__ __forceinline__ uint64_t polr_router_step_absorb(DevMpx *m, DevMpx *mg, unsigned long long *counts,
+                                                            uint32_t k, uint32_t lane, bool coherent, bool discard) {
+	uint64_t s = 0;
+	for (uint32_t j0 = 0; j0 < k; j0 += 2) {
+		const uint32_t j = j0 + (lane >> 5);
+		const uint32_t shard = lane & 31u;
+		unsigned long long v = 0;
+		if (j < k) {
+			if (coherent) {
+				v = atomicExch(&counts[(uint64_t)shard * k + j], 0ull);
+			} else {
+				v = counts[(uint64_t)shard * k + j];
+				counts[(uint64_t)shard * k + j] = 0;
+			}
+		}
+		for (int d = 16; d > 0; d >>= 1) {
+			v += __shfl_down(v, d, 32);
+		}
+		const unsigned long long v_hi = __shfl(v, 32, 64);
+		if (lane == 0 && !discard) {
+			// (fire-and-forget adds: a load-add-store here would put an HBM round trip on the routing path)
+			s += v;
+			if (v) {
+				atomicAdd((unsigned long long *)&mg->stage_out[m->last_path][j0], v);
+			}
+			if (j0 + 1 < k) {
+				s += v_hi;
+				if (v_hi) {
+					atomicAdd((unsigned long long *)&mg->stage_out[m->last_path][j0 + 1], v_hi);
+				}
+			}
+		}
+	}
+	return s;
+}
+
 __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, DevRound *round,
                                                       uint64_t *unit_prefix, uint32_t *unit_size_out,
                                                       unsigned long long *counts, uint32_t k, uint32_t resident_waves,
                                                       uint32_t lane, bool coherent, const OffsCache *oc, bool discard) {
-	// absorb the previous round's per-join outputs: what RunPath feeds AddNumIntermediates (:486-487).
-	// One wave: lane s sums shard s of the k counters, a shuffle tree adds the shards, lane 0 routes.
-	uint64_t s = 0;
-	{
-		// two counters per pass: lanes 0..31 sum the shards of counter j, lanes 32..63 those of j+1
-		for (uint32_t j0 = 0; j0 < k; j0 += 2) {
-			const uint32_t j = j0 + (lane >> 5);
-			const uint32_t shard = lane & 31u;
-			unsigned long long v = 0;
-			if (j < k) {
-				if (coherent) {
-					v = atomicExch(&counts[(uint64_t)shard * k + j], 0ull);
-				} else {
-					v = counts[(uint64_t)shard * k + j];
-					counts[(uint64_t)shard * k + j] = 0;
-				}
-			}
-			for (int d = 16; d > 0; d >>= 1) {
-				v += __shfl_down(v, d, 32);
-			}
-			const unsigned long long v_hi = __shfl(v, 32, 64);
-			if (lane == 0 && !discard) {
-				// (fire-and-forget adds: a load-add-store here would put an HBM round trip on the routing path)
-				s += v;
-				if (v) {
-					atomicAdd((unsigned long long *)&mg->stage_out[m->last_path][j0], v);
-				}
-				if (j0 + 1 < k) {
-					s += v_hi;
-					if (v_hi) {
-						atomicAdd((unsigned long long *)&mg->stage_out[m->last_path][j0 + 1], v_hi);
-					}
-				}
-			}
-		}
-		if (lane != 0) {
-			return;
-		}
+	const uint64_t s = polr_router_step_absorb(m, mg, counts, k, lane, coherent, discard);
+	if (lane != 0) {
+		return;
 	}
-	polr::MultiplexerCore &core = m->core;
-	core.AddNumIntermediates(s);
+	m->core.AddNumIntermediates(s);
 	m->num_intermediates_total += s;
+	polr_router_route(m, round, unit_prefix, unit_size_out, resident_waves, oc);
+}
 
+// The routing decision proper (lane 0 of the caller): FinalizePathRun of the run whose intermediates have just
+// been added, Route, fold the routing window, write the round.  m: the state to work on.
+__device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, uint64_t *unit_prefix,
+                                                  uint32_t *unit_size_out, uint32_t resident_waves,
+                                                  const OffsCache *oc) {
+	polr::MultiplexerCore &core = m->core;
 	round->begin = 0;
 	round->count = 0;
 	round->path = 0;
@@ -275,13 +290,16 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 
 #define POLR_RES_COPIES 64 // the round words are published in 64 copies (one per router lane, own cache line)
 #define POLR_RES_ARRIVE 32 // arrival counter shards (own cache line each)
+// Two round SLOTS per executor: while the workers probe round r the router may already have published round
+// r+1 in the other slot when its decision cannot depend on r's intermediates (the exploration rounds of an init
+// phase, ALTERNATE): two dependent-latency rounds overlap.  Each slot has its own words, counter bank and arrivals.
 struct ResidentSync {
 	struct {
-		unsigned long long a, b, pad[6];
+		unsigned long long a[2], b[2], pad[4];
 	} pub[POLR_RES_COPIES]; // workgroup w polls copy w % 64: a few pollers per line instead of a thousand
 	struct {
 		unsigned long long v, pad[7];
-	} arrived[POLR_RES_ARRIVE]; // monotonic across runs; the router sums the shards
+	} arrived[2][POLR_RES_ARRIVE]; // per slot; monotonic across runs; the router sums the shards
 };
 
 struct ResidentExec {
@@ -309,7 +327,7 @@ struct ResidentExec {
 #endif
 
 #define POLR_RES_HOT_DWORDS (offsetof(DevMpx, stage_out) / 4)
-#define POLR_RES_ROUTER_DWORDS (POLR_RES_HOT_DWORDS + 16)
+#define POLR_RES_ROUTER_DWORDS (POLR_RES_HOT_DWORDS + 32)
 
 __device__ __forceinline__ unsigned long long polr_res_word_a(uint32_t epoch, uint32_t round, uint32_t count) {
 	return ((unsigned long long)(epoch & 0xFFFu) << 52) | ((unsigned long long)(round & 0xFFFFFu) << 32) | count;
@@ -360,10 +378,10 @@ __device__ __forceinline__ void polr_write_stats(const DevMpx *m, DevMpx *mg, po
 }
 
 // sum of the arrival shards, the same value in every lane (full wave)
-__device__ __forceinline__ unsigned long long polr_res_arrived(ResidentSync *sync, uint32_t lane) {
+__device__ __forceinline__ unsigned long long polr_res_arrived(ResidentSync *sync, uint32_t slot, uint32_t lane) {
 	unsigned long long v = 0;
 	if (lane < POLR_RES_ARRIVE) {
-		v = __hip_atomic_load(&sync->arrived[lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		v = __hip_atomic_load(&sync->arrived[slot][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	for (int d = 16; d > 0; d >>= 1) {
 		v += __shfl_xor(v, d, 64);
@@ -382,12 +400,59 @@ __device__ __forceinline__ void polr_offs_cache_fill(OffsCache &oc, const Reside
 		n = cap;
 	}
 	__builtin_amdgcn_wave_barrier();
-	for (uint64_t i = lane; i < n; i += 64) {
-		oc.data[i] = x.chunk_offsets[from + i];
+	// 8 independent loads per lane in flight (a plain loop waits for every load before it issues the next one)
+	for (uint64_t i0 = 0; i0 < n; i0 += 64 * 8) {
+		uint64_t v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const uint64_t i = i0 + (uint64_t)j * 64 + lane;
+			v[j] = i < n ? x.chunk_offsets[from + i] : 0;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const uint64_t i = i0 + (uint64_t)j * 64 + lane;
+			if (i < n) {
+				oc.data[i] = v[j];
+			}
+		}
 	}
 	__builtin_amdgcn_wave_barrier();
 	oc.base = from;
 	oc.n = n;
+}
+
+// May the decision AFTER the round just routed be made before that round's intermediates are known?
+// Yes exactly when it is an exploration round of an init phase (or ALTERNATE): FinalizePathRun will store a
+// non-zero resistance for the current path whatever the intermediates are (r = I/T + 0.5 > 0), so
+//   INIT_ONCE:                        the next path is num_paths_initialized (routing_strategy.cpp:55-82),
+//   ADAPTIVE_REINIT / EXP. BACKOFF:   the next path is the first one whose resistance is still 0, other than the
+//                                     current one (FirstUninitialised, :94-180 / :198-252),
+// and the tuple count is min(init_tuple_count, rest of the chunk) (:84-92, :182-196, :254-265) -- none of which
+// reads a reward.  ALTERNATE cycles through the paths per chunk (:440-452).  Everything else: no.
+__device__ __forceinline__ bool polr_can_speculate(const volatile polr::MultiplexerCore &core) {
+	if (core.num_cache_flushing_skips != 0) {
+		return false; // a routing window is open
+	}
+	switch (core.routing) {
+	case polr::ALTERNATE:
+		return true;
+	case polr::INIT_ONCE:
+		return !core.init_phase_done && core.num_paths_initialized < core.path_count;
+	case polr::ADAPTIVE_REINIT:
+	case polr::EXPONENTIAL_BACKOFF: {
+		if (core.init_phase_done) {
+			return false;
+		}
+		for (uint32_t i = 0; i < core.path_count; i++) {
+			if (i != core.current_path_idx && core.path_resistances[i] == 0) {
+				return true;
+			}
+		}
+		return false;
+	}
+	default:
+		return false;
+	}
 }
 
 // The router of one executor: ONE full wave, for the whole run.  lds: POLR_RES_ROUTER_DWORDS dwords.
@@ -395,7 +460,7 @@ __device__ __forceinline__ void polr_offs_cache_fill(OffsCache &oc, const Reside
 // registered: the executor's registration counter; wpb: waves per worker workgroup.
 __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint32_t k, uint32_t *registered,
                                                      uint32_t wpb, uint32_t lane, uint32_t *lds, uint64_t *cache_lds,
-                                                     uint32_t cache_cap) {
+                                                     uint32_t cache_cap, uint32_t *scratch_lds) {
 	DevMpx *mg = x.mpx;
 	{
 		const uint32_t *src = (const uint32_t *)mg;
@@ -445,17 +510,47 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		m->n_tuples = x.n_tuples;
 		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
 	}
-	unsigned long long target = polr_res_arrived(x.sync, lane);
+	const size_t bank_stride = (size_t)POLR_NSHARD * POLR_KMAX;
+	unsigned long long target[2] = {polr_res_arrived(x.sync, 0, lane), polr_res_arrived(x.sync, 1, lane)};
+	if (reset) {
+		// drop whatever the second counter bank still holds (the first is dropped by the first step)
+		polr_router_step_absorb(m, mg, x.counts + bank_stride, k, lane, true, true);
+	}
 	uint32_t round_no = 0;
 	uint32_t n_steps = 0;
+	uint32_t n_pub = 0;          // rounds published so far: the next one goes to slot n_pub & 1
+	bool have_pending = false;   // a published round whose counters have not been absorbed yet ...
+	uint32_t pend_slot = 0;      // ... in this slot
+	bool have_spec = false;      // the round after it is published too (speculated), descriptor kept for the check
+	unsigned long long spec_bw = 0;
+	uint32_t spec_count = 0, spec_blocks = 0;
+	bool failed = false, finished = false;
 	while (true) {
 		__builtin_amdgcn_wave_barrier();
 		if (lane == 0) {
 			RES_STAMP(x, n_steps, 0)
 		}
-		// the round is dealt to the worker workgroups that have started by now (at least one)
-		uint32_t n_blocks = 0;
-		{
+		// (1) the oldest round in flight has to be complete before its counters can be absorbed
+		if (have_pending) {
+			const unsigned long long t0 = wall_clock64();
+			while (polr_res_arrived(x.sync, pend_slot, lane) != target[pend_slot]) {
+				__builtin_amdgcn_s_sleep(1);
+				if (wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
+					failed = true; // a worker is missing
+					break;
+				}
+			}
+			if (lane == 0) {
+				RES_STAMP(x, n_steps, 2)
+			}
+			if (failed) {
+				break;
+			}
+		}
+		// (2) the real step.  The round it routes is dealt to the worker workgroups that have started by now
+		// (at least one) -- or to those its speculated twin was dealt to
+		uint32_t n_blocks = spec_blocks;
+		if (!have_spec) {
 			const unsigned long long t0 = wall_clock64();
 			while (true) {
 				n_blocks = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -466,41 +561,112 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 			}
 			n_blocks = __shfl(n_blocks, 0, 64);
 			n_blocks = n_blocks > 4095u ? 4095u : n_blocks;
+			if (n_blocks == 0) {
+				failed = true; // not one worker workgroup got onto the device in 4 s
+				break;
+			}
 		}
 		// (a reset run drops whatever the counters still hold: first step only)
-		polr_router_step_impl(m, mg, round, prefix, us, x.counts, k, (n_blocks ? n_blocks : 1u) * wpb, lane, true, &oc,
-		                      reset && n_steps == 0);
-		__builtin_amdgcn_wave_barrier();
-		// (all lanes read what lane 0 left in LDS)
-		round_no = polr_res_next_round(round_no);
-		const bool done = ((volatile DevMpx *)m)->done != 0;
-		if (done) {
-			__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, POLR_RES_DONE), __ATOMIC_RELAXED,
-			                   __HIP_MEMORY_SCOPE_AGENT);
-			break;
-		}
-		const volatile DevRound *vr = round;
-		if (n_blocks == 0) {
-			// not one worker workgroup got onto the device in 4 s: give up (reported like a lost worker)
-			__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, POLR_RES_DONE), __ATOMIC_RELAXED,
-			                   __HIP_MEMORY_SCOPE_AGENT);
-			if (lane == 0 && host_words) {
-				host_words[2] = 1;
+		{
+			const uint64_t got = polr_router_step_absorb(m, mg, x.counts + (have_pending ? pend_slot : 0u) * bank_stride,
+			                                             k, lane, true, reset && n_steps == 0);
+			if (lane == 0) {
+				m->core.AddNumIntermediates(got);
+				m->num_intermediates_total += got;
 			}
-			break;
 		}
-		const unsigned long long bw = (unsigned long long)(uint32_t)vr->begin |
-		                              ((unsigned long long)((((volatile uint32_t *)us)[0] >> 6) & 63u) << 32) |
-		                              ((unsigned long long)(vr->path & 31u) << 38) |
-		                              ((unsigned long long)(vr->emit & 1u) << 43) |
-		                              ((unsigned long long)(n_blocks & 0xFFFu) << 44) |
-		                              ((unsigned long long)polr_res_tag(x.epoch, round_no) << 56);
-		__hip_atomic_store(&x.sync->pub[lane].b, bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(&x.sync->pub[lane].a, polr_res_word_a(x.epoch, round_no, (uint32_t)vr->count),
-		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		target += ((volatile uint64_t *)prefix)[1];
-		if (lane == 0) {
-			RES_STAMP(x, n_steps, 1)
+		n_steps++;
+		// Two passes over ONE inlined copy of the routing code (two call sites would double the router's register
+		// pressure): pass 0 is the real step on the state, pass 1 -- only if the decision after it cannot depend
+		// on the intermediates of the round just routed -- rehearses the next step on a copy and publishes it in
+		// the other slot.
+		bool stop = false;
+		for (uint32_t pass = 0; pass < 2 && !stop; pass++) {
+			__builtin_amdgcn_wave_barrier();
+			if (pass == 1) {
+				if (have_spec || !polr_can_speculate(((volatile DevMpx *)m)->core)) {
+					break;
+				}
+				// the rehearsal runs IN PLACE (the routing code then only ever sees the one LDS object, which keeps
+				// its accesses LDS instructions); the state is saved here and put back below
+				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+					scratch_lds[i] = lds[i];
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) {
+					m->log_enabled = 0; // (no trace of the rehearsal)
+				}
+			}
+			if (lane == 0) {
+				polr_router_route(m, round, prefix, us, n_blocks * wpb, &oc);
+			}
+			__builtin_amdgcn_wave_barrier();
+			// (all lanes read what lane 0 left in LDS)
+			DevMpx *tgt = m;
+			DevRound *rd = round;
+			uint64_t *pf = prefix;
+			uint32_t *uu = us;
+			const bool done = ((volatile DevMpx *)tgt)->done != 0;
+			const volatile DevRound *vr = rd;
+			const unsigned long long bw_base = (unsigned long long)(uint32_t)vr->begin |
+			                                   ((unsigned long long)((((volatile uint32_t *)uu)[0] >> 6) & 63u) << 32) |
+			                                   ((unsigned long long)(vr->path & 31u) << 38) |
+			                                   ((unsigned long long)(vr->emit & 1u) << 43) |
+			                                   ((unsigned long long)(n_blocks & 0xFFFu) << 44);
+			const uint32_t cnt = (uint32_t)vr->count;
+			const uint64_t n_units_routed = ((volatile uint64_t *)pf)[1];
+			if (pass == 1) {
+				__builtin_amdgcn_wave_barrier();
+				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+					lds[i] = scratch_lds[i];
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			if (pass == 0 && have_spec) {
+				// this round is already out: the real decision must be the speculated one, bit for bit
+				if (done || bw_base != spec_bw || cnt != spec_count) {
+					failed = true; // (cannot happen while polr_can_speculate is right; never continue on a wrong round)
+					stop = true;
+					break;
+				}
+				have_spec = false;
+				pend_slot ^= 1u;
+				continue;
+			}
+			if (done) {
+				if (pass == 0) {
+					round_no = polr_res_next_round(round_no);
+					__hip_atomic_store(&x.sync->pub[lane].a[n_pub & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
+					                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					finished = true;
+					stop = true;
+				}
+				break; // (a rehearsal that runs off the end of the source publishes nothing)
+			}
+			round_no = polr_res_next_round(round_no);
+			const uint32_t slot = n_pub & 1u;
+			__hip_atomic_store(&x.sync->pub[lane].b[slot],
+			                   bw_base | ((unsigned long long)polr_res_tag(x.epoch, round_no) << 56), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&x.sync->pub[lane].a[slot], polr_res_word_a(x.epoch, round_no, cnt), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+			target[slot] += n_units_routed;
+			n_pub++;
+			if (pass == 0) {
+				pend_slot = slot;
+				have_pending = true;
+				if (lane == 0) {
+					RES_STAMP(x, n_steps - 1, 1)
+				}
+			} else {
+				have_spec = true;
+				spec_bw = bw_base;
+				spec_count = cnt;
+				spec_blocks = n_blocks;
+			}
+		}
+		if (stop) {
+			break;
 		}
 		// while the workers probe: keep the boundaries of the chunks ahead in LDS
 		{
@@ -509,28 +675,17 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 				polr_offs_cache_fill(oc, x, ci, cache_cap, lane);
 			}
 		}
-		const unsigned long long t0 = wall_clock64();
-		bool lost = false;
-		while (polr_res_arrived(x.sync, lane) != target) {
-			__builtin_amdgcn_s_sleep(1);
-			if (wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
-				lost = true;
-				break;
-			}
-		}
-		if (lane == 0) {
-			RES_STAMP(x, n_steps, 2)
-		}
-		n_steps++;
-		if (lost) {
-			// a worker is missing: release everybody and report (host: progress word 2)
-			__hip_atomic_store(&x.sync->pub[lane].a,
-			                   polr_res_word_a(x.epoch, polr_res_next_round(round_no), POLR_RES_DONE), __ATOMIC_RELAXED,
-			                   __HIP_MEMORY_SCOPE_AGENT);
-			if (lane == 0 && host_words) {
-				host_words[2] = 1;
-			}
-			break;
+	}
+	if (failed) {
+		// release everybody (in both slots) and report (host: progress word 2)
+		round_no = polr_res_next_round(round_no);
+		__hip_atomic_store(&x.sync->pub[lane].a[n_pub & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
+		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		round_no = polr_res_next_round(round_no);
+		__hip_atomic_store(&x.sync->pub[lane].a[(n_pub + 1) & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
+		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (lane == 0 && host_words) {
+			host_words[2] = 1;
 		}
 	}
 	__builtin_amdgcn_wave_barrier();

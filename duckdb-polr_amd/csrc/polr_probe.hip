@@ -930,6 +930,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	__shared__ __attribute__((aligned(16))) uint32_t router_lds[POLR_RES_ROUTER_DWORDS];
 	__shared__ unsigned long long bcast[2][2];
+	__shared__ uint32_t bcast_slot[2];
 	const uint32_t wave_in_block = threadIdx.x >> 6;
 	const uint32_t wpb = blockDim.x >> 6;
 	const uint32_t e = blockIdx.x % n_exec;
@@ -954,8 +955,10 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	if (b == 0) {
 		if (wave_in_block == 0) {
 			const uint32_t dyn_dwords = wpb * per_wave_dwords<W, K>();
+			// the router workgroup's dynamic LDS: [chunk-offset window | copy of the state for speculation]
+			const uint32_t scratch_dwords = (POLR_RES_HOT_DWORDS + 1u) & ~1u;
 			polr_resident_router(x, k, &execs[e].registered, wpb, threadIdx.x & 63, router_lds, (uint64_t *)lds,
-			                     dyn_dwords / 2);
+			                     (dyn_dwords - scratch_dwords) / 2, lds + (dyn_dwords - scratch_dwords));
 		}
 		return;
 	}
@@ -995,16 +998,26 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	__syncthreads();
 	const uint32_t reg_rank = reg_rank_s;
 	const uint32_t epoch12 = x.epoch & 0xFFFu;
-	uint32_t my_round = 0; // (thread 0 only)
+	uint32_t seen[2] = {0, 0}; // (thread 0 only) last round taken from each slot
 	const uint32_t copy = b % POLR_RES_COPIES;
 	uint32_t it = 0;
 	while (true) {
 		if (threadIdx.x == 0) {
-			unsigned long long a, bw = 0;
+			unsigned long long a = POLR_RES_DONE, bw = 0;
+			uint32_t slot = 0;
 			const unsigned long long t0 = wall_clock64();
 			while (true) {
-				a = __hip_atomic_load(&x.sync->pub[copy].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((uint32_t)(a >> 52) == epoch12 && ((uint32_t)(a >> 32) & 0xFFFFFu) != my_round) {
+				const unsigned long long a0 =
+				    __hip_atomic_load(&x.sync->pub[copy].a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const unsigned long long a1 =
+				    __hip_atomic_load(&x.sync->pub[copy].a[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t r0 = (uint32_t)(a0 >> 32) & 0xFFFFFu, r1 = (uint32_t)(a1 >> 32) & 0xFFFFFu;
+				const bool new0 = (uint32_t)(a0 >> 52) == epoch12 && r0 != seen[0];
+				const bool new1 = (uint32_t)(a1 >> 52) == epoch12 && r1 != seen[1];
+				if (new0 || new1) {
+					// both new: the earlier round first (the router numbers the rounds consecutively)
+					slot = (new0 && new1) ? (polr_res_next_round(r0) == r1 ? 0u : 1u) : (new0 ? 0u : 1u);
+					a = slot ? a1 : a0;
 					break;
 				}
 				__builtin_amdgcn_s_sleep(8);
@@ -1014,10 +1027,11 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 				}
 			}
 			if ((uint32_t)a != POLR_RES_DONE) {
-				my_round = (uint32_t)(a >> 32) & 0xFFFFFu;
-				const uint32_t tag = polr_res_tag(x.epoch, my_round);
+				const uint32_t r = (uint32_t)(a >> 32) & 0xFFFFFu;
+				seen[slot] = r;
+				const uint32_t tag = polr_res_tag(x.epoch, r);
 				while (true) {
-					bw = __hip_atomic_load(&x.sync->pub[copy].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					bw = __hip_atomic_load(&x.sync->pub[copy].b[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					if ((uint32_t)(bw >> 56) == tag) {
 						break;
 					}
@@ -1030,6 +1044,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 			}
 			bcast[it & 1][0] = a;
 			bcast[it & 1][1] = bw;
+			bcast_slot[it & 1] = slot;
 			if (b == 1) {
 				RES_STAMP(x, it, 3)
 			}
@@ -1037,6 +1052,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 		__syncthreads();
 		const unsigned long long a = bcast[it & 1][0];
 		const unsigned long long bw = bcast[it & 1][1];
+		const uint32_t slot = uni(bcast_slot[it & 1]);
 		it++;
 		const uint32_t count = uni((uint32_t)a);
 		if (count == POLR_RES_DONE) {
@@ -1049,7 +1065,11 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 		const uint32_t n_blocks = uni((uint32_t)(bw >> 44) & 0xFFFu); // workgroups this round is dealt to
 		const uint32_t n_units = (count + us - 1) / us;
 		// small rounds spread over the CUs: consecutive units go to different workgroups
-		const uint32_t first_unit = reg_rank + n_blocks * wave_in_block;
+		// (a round in slot 1 is dealt from the middle of the workgroups, so that two small rounds in flight land on
+		// different workgroups)
+		const uint32_t rot = slot ? n_blocks / 2 : 0u;
+		const uint32_t my_block = reg_rank < n_blocks ? (reg_rank >= rot ? reg_rank - rot : reg_rank + n_blocks - rot) : 0u;
+		const uint32_t first_unit = my_block + n_blocks * wave_in_block;
 		if (reg_rank < n_blocks && first_unit < n_units) {
 			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)pidx * POLR_KMAX);
 			uint32_t *dst = (uint32_t *)c.desc;
@@ -1069,11 +1089,11 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 				my_units++;
 			}
 			run_until_idle(c, true);
-			flush_counts(c, x.counts, 0);
+			flush_counts(c, x.counts + (size_t)slot * POLR_NSHARD * POLR_KMAX, 0);
 			if (c.lane == 0) {
 				// flush_token carries the returned values of the counter atomics: the arrival is issued after
 				// they have been performed
-				atomicAdd(&x.sync->arrived[b % POLR_RES_ARRIVE].v, (unsigned long long)my_units + c.flush_token);
+				atomicAdd(&x.sync->arrived[slot][b % POLR_RES_ARRIVE].v, (unsigned long long)my_units + c.flush_token);
 				if (b == 1 && wave_in_block == 0) {
 					RES_STAMP(x, it - 1, 4)
 				}

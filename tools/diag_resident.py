@@ -36,7 +36,5 @@ for e in range(min(E, 2)):
     for i in range(n):
         r = buf[i].astype(np.int64)
         if r[0] == 0: continue
-        print(i, "t=%.2fus" % ((int(r[0]) - t00) / 100.0), "step->pub %.2f" % ((r[1]-r[0])/100.0) if r[1] else "",
-              "pub->seen %.2f" % ((r[3]-r[1])/100.0) if r[3] and r[1] else "",
-              "seen->w_arrived %.2f" % ((r[4]-r[3])/100.0) if r[4] and r[3] else "",
-              "pub->all_arrived %.2f" % ((r[2]-r[1])/100.0) if r[2] and r[1] else "")
+        f = lambda v: "%.2f" % ((int(v) - t00) / 100.0) if v else "-"
+        print(i, "step_begin", f(r[0]), "arrived(prev)", f(r[2]), "published", f(r[1]), "| worker1: seen", f(r[3]), "arrived", f(r[4]))
