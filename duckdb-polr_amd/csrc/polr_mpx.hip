@@ -101,7 +101,6 @@ __global__ void polr_mpx_init_kernel(DevMpx *m, polr_mpx_config cfg, uint32_t n_
 	m->wide0_mask = wide0_mask;
 	m->cfg = cfg;
 	m->n_paths = n_paths;
-	m->pad4 = 0;
 	m->pad2 = 0;
 	m->progress = progress;
 	m->steps_done = steps_done_init; // monotonic across resets: the host throttles on differences
@@ -228,6 +227,13 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	m->cfg.max_log_rounds = (uint32_t)max_log;
 	// every stage 0 takes wide (256-tuple) steps, so units are multiples of 256 tuples
 	m->wide0_mask = p->n_paths >= 32 ? 0xFFFFFFFFu : ((1u << p->n_paths) - 1u);
+	// (zero first: the bookkeeping of resident runs, res_valid / res_target, is not touched by the init kernel --
+	// a host-side reset keeps it)
+	e = hipMemsetAsync(m->dev, 0, sizeof(DevMpx), ctx->stream);
+	if (e != hipSuccess) {
+		polr_mpx_destroy(m);
+		POLR_FAIL(ctx, POLR_E_HIP, "multiplexer init failed: %s", hipGetErrorString(e));
+	}
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, ctx->stream, m->dev, m->cfg, p->n_paths, p->n_tuples,
 	                   m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask, m->progress_dev, 0u);
 	e = hipStreamSynchronize(ctx->stream);

@@ -32,10 +32,15 @@ struct DevMpx {
 	// host-visible progress words (pinned, mapped host memory): [0] = routing steps completed, [1] = done
 	volatile uint32_t *progress;
 	uint32_t steps_done, pad3;
-	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
-	// cold: what a fresh MultiplexerState is built from (a resident run can reset itself)
+	// what a fresh MultiplexerState is built from (a resident run can reset itself)
 	polr_mpx_config cfg;
-	uint32_t n_paths, pad4;
+	uint32_t n_paths;
+	// bookkeeping of resident runs, carried from run to run so that a run starts without extra round trips:
+	// res_valid: res_target[] are the current sums of the two arrival counters and counter bank 1 is empty
+	// (false after a run that was given up -- the next one re-reads and drops)
+	uint32_t res_valid;
+	unsigned long long res_target[2];
+	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
 };
 
 // window of the chunk-offset array kept in LDS by a resident router (the boundaries a routing step needs
@@ -462,10 +467,25 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
                                                      uint32_t wpb, uint32_t lane, uint32_t *lds, uint64_t *cache_lds,
                                                      uint32_t cache_cap, uint32_t *scratch_lds) {
 	DevMpx *mg = x.mpx;
+	if (lane == 0) {
+		RES_STAMP(x, 0, 5)
+	}
 	{
+		// (independent loads, all in flight together: a plain copy loop waits for every load before the next)
 		const uint32_t *src = (const uint32_t *)mg;
-		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
-			lds[i] = src[i];
+		constexpr uint32_t kPer = (POLR_RES_HOT_DWORDS + 63) / 64;
+		uint32_t v[kPer];
+#pragma unroll
+		for (uint32_t j = 0; j < kPer; j++) {
+			const uint32_t i = j * 64 + lane;
+			v[j] = i < POLR_RES_HOT_DWORDS ? src[i] : 0u;
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < kPer; j++) {
+			const uint32_t i = j * 64 + lane;
+			if (i < POLR_RES_HOT_DWORDS) {
+				lds[i] = v[j];
+			}
 		}
 	}
 	DevMpx *m = (DevMpx *)lds;
@@ -493,8 +513,8 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 			mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = 0;
 		}
 		if (lane == 0) {
-			const polr_mpx_config cfg = mg->cfg;
-			m->core.Init(cfg.routing, mg->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
+			const polr_mpx_config cfg = m->cfg;
+			m->core.Init(cfg.routing, m->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
 			m->num_intermediates_total = 0;
 			m->num_rounds = 0;
 			m->n_log = 0;
@@ -511,9 +531,16 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
 	}
 	const size_t bank_stride = (size_t)POLR_NSHARD * POLR_KMAX;
-	unsigned long long target[2] = {polr_res_arrived(x.sync, 0, lane), polr_res_arrived(x.sync, 1, lane)};
-	if (reset) {
-		// drop whatever the second counter bank still holds (the first is dropped by the first step)
+	__builtin_amdgcn_wave_barrier();
+	unsigned long long target[2];
+	if (((volatile DevMpx *)m)->res_valid) {
+		target[0] = ((volatile DevMpx *)m)->res_target[0];
+		target[1] = ((volatile DevMpx *)m)->res_target[1];
+	} else {
+		// first resident run of this multiplexer, or the previous one was given up: read the arrival counters and
+		// drop whatever the second counter bank still holds (the first is dropped / absorbed by the first step)
+		target[0] = polr_res_arrived(x.sync, 0, lane);
+		target[1] = polr_res_arrived(x.sync, 1, lane);
 		polr_router_step_absorb(m, mg, x.counts + bank_stride, k, lane, true, true);
 	}
 	uint32_t round_no = 0;
@@ -698,6 +725,9 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 	}
 	__builtin_amdgcn_wave_barrier();
 	if (lane == 0) {
+		m->res_valid = failed ? 0u : 1u;
+		m->res_target[0] = target[0];
+		m->res_target[1] = target[1];
 		m->progress = host_words;
 		if (host_words) { // what a per-round run would have published: the run is over
 			host_words[1] = m->done;
@@ -710,5 +740,8 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
 			dst[i] = lds[i];
 		}
+	}
+	if (lane == 0) {
+		RES_STAMP(x, 0, 6)
 	}
 }

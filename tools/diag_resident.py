@@ -33,6 +33,7 @@ for e in range(min(E, 2)):
     path, tuples, inter = mpxs[e].fetch_log()
     print("executor", e, "rounds:", list(zip(path.tolist(), tuples.tolist())))
     t00 = int(buf[0][0])
+    print("router entry %.2f us before its first step, router exit at %.2f us" % ((t00 - int(buf[0][5])) / 100.0, (int(buf[0][6]) - t00) / 100.0))
     for i in range(n):
         r = buf[i].astype(np.int64)
         if r[0] == 0: continue
