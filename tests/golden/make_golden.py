@@ -264,8 +264,55 @@ def make_job_light(scale=0.1):
     return gold
 
 
+def make_ssb(sf=0.2):
+    """BASELINE.json configs[2] (SSB-skew 4-way star join, 3 alternative probe orders multiplexed) at reduced
+    scale: ALTERNATE matrix, COUNT(*) and the routing traces of the six strategies, from the reference"""
+    wl = workloads.ssb_skew_q41(sf=sf)
+    gold = {"scenario": "ssb_skew_q41", "sf": sf, "max_join_orders": 3, "join_enumerator": "dfs_min_card", "routing": {}}
+    # (each_last_once / each_first_once with max_join_orders below the number of joins end in vector::reserve /
+    # bad_alloc in the reference: dfs_min_card is the deterministic enumerator that yields exactly 3 orders here)
+    base = ["PRAGMA enable_polr", "PRAGMA enable_log_tuples_routed", "PRAGMA disable_caching",
+            "SET join_enumerator TO 'dfs_min_card'", "SET max_join_orders TO 3"]
+    r = run_reference(wl, base + ["SET multiplexer_routing TO 'alternate'"], select="count(*)")
+    gold["alternate"] = {"matrix": parse_alt(r["log_csv"][0]), "intms": r["intms"][0]}
+    gold["count_star"] = int(r["rows"][0][0])
+    gold["explain"] = r["explain"]
+    # Which join orders did the reference enumerate?  dfs_min_card ranks joins by the planner's estimated
+    # cardinality of each JOIN node (polar_enumeration_algo.cpp:24-25), a statistic of the out-of-scope optimizer
+    # that it does not log.  The ALTERNATE matrix identifies them: column p must equal the per-chunk
+    # intermediates of exactly one permutation of the joins (all 1172 chunks; computed with the oracle).
+    import itertools
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    import common
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    want = np.asarray(gold["alternate"]["matrix"], dtype=np.uint64)
+    k = len(ojoins)
+    found = {}
+    for perm in itertools.permutations(range(k)):
+        res = common.orc.run_pipeline(pcols, ojoins, [list(perm)], routing="alternate", caching=False,
+                                      collect_output=False)
+        col = res["alt_matrix"][:, 0]
+        for p in range(want.shape[1]):
+            if np.array_equal(col, want[:, p]):
+                found.setdefault(p, []).append(list(perm))
+    assert all(len(found.get(p, [])) == 1 for p in range(want.shape[1])), found
+    gold["paths"] = [found[p][0] for p in range(want.shape[1])]
+    for routing in ROUTINGS:
+        rr = run_reference(wl, base + ["SET multiplexer_routing TO '%s'" % routing], select="count(*)")
+        assert int(rr["rows"][0][0]) == gold["count_star"]
+        gold["routing"][routing] = {"rounds": parse_rounds(rr["log_csv"][0]), "intms": rr["intms"][0],
+                                    "tuple_counts": rr["tuple_counts"][0]}
+    return gold
+
+
 def main():
-    names = sys.argv[1:] or list(SCENARIOS) + ["job_light_01"]
+    names = sys.argv[1:] or list(SCENARIOS) + ["job_light_01", "ssb_skew_q41"]
+    if "ssb_skew_q41" in names:
+        names = [n for n in names if n != "ssb_skew_q41"]
+        gold = make_ssb()
+        path = os.path.join(HERE, "ssb_skew_q41.json")
+        json.dump(gold, open(path, "w"), separators=(",", ":"))
+        print("wrote", path, os.path.getsize(path), "bytes")
     if "job_light_01" in names:
         names = [n for n in names if n != "job_light_01"]
         gold = make_job_light()
