@@ -254,6 +254,29 @@ def ssb_skew_q41(sf=1.0, seed=SEED, n_lineorder=None):
     return {"name": "ssb_skew_q41", "probe": {"name": "lineorder", "cols": lineorder}, "joins": [jc, js, jp, jd]}
 
 
+def ssb_q11(sf=0.2, seed=SEED):
+    """BASELINE.json configs[0]: SSB Q1.1 shape -- lineorder x date, filters on both sides (SURVEY 8(d) cfg 1:
+    orderdate uniform over the 2 556 date keys, discount U[0,10], quantity U[1,50], extendedprice; d_year = 1993,
+    lo_discount BETWEEN 1 AND 3, lo_quantity < 25).  One join: the plain (non-multiplexed) path."""
+    rng = _rng(seed, 11)
+    n_lo = int(6_000_000 * sf)
+    n_d = 2556
+    d_keys = (19920101 + np.arange(n_d)).astype(np.uint32)
+    d_year = (1992 + np.arange(n_d) * 7 // n_d).astype(np.uint16)
+    lineorder = {"lo_orderdate": d_keys[rng.integers(0, n_d, n_lo)],
+                 "lo_discount": rng.integers(0, 11, n_lo).astype(np.uint16),
+                 "lo_quantity": rng.integers(1, 51, n_lo).astype(np.uint16),
+                 "lo_extendedprice": rng.integers(90_000, 10_000_000, n_lo).astype(np.uint32)}
+    keep = d_year == 1993
+    jd = {"name": "date", "keys": [d_keys[keep]], "key_names": ["d_datekey"], "payload": {"d_year": d_year[keep]},
+          "key_src": [(-1, 0)], "perfect": None}
+    return {"name": "ssb_q11", "probe": {"name": "lineorder", "cols": lineorder,
+                                         "filter": [("lo_discount", ">=", 1), ("lo_discount", "<=", 3),
+                                                    ("lo_quantity", "<", 25)]},
+            "joins": [jd], "date_full": {"d_datekey": d_keys, "d_year": d_year},
+            "sql_where": "d_year = 1993 AND lo_discount >= 1 AND lo_discount <= 3 AND lo_quantity < 25"}
+
+
 def default_paths(k, kind="each_last_once"):
     """Join orders a deterministic enumerator of the reference yields when no join depends on
     another (EachLastOnceEnumeration / EachFirstOnceEnumeration, polar_enumeration_algo.cpp:610-667)."""

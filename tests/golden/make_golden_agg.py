@@ -13,9 +13,45 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "duckdb-polr_amd", "python"))
+
+
+def make_ssb_q11():
+    """BASELINE.json configs[0] (SSB Q1.1 shape) through the reference: filtered scan of lineorder, filtered date
+    build side, ungrouped aggregates -> tests/golden/ssb_q11.json"""
+    import shutil
+    import subprocess
+    import tempfile
+    from polr_amd import workloads
+    wl = workloads.ssb_q11()
+    workdir = tempfile.mkdtemp(prefix="polr_golden_")
+    try:
+        lines = []
+        mg.table_script(lines, workdir, "lineorder", wl["probe"]["cols"])
+        mg.table_script(lines, workdir, "date", wl["date_full"])
+        exprs = ["count(*)", "sum(lo_extendedprice)", "min(lo_extendedprice)", "max(lo_extendedprice)", "max(lo_quantity)",
+                 "min(lo_discount)", "sum(lo_discount)", "sum(d_year)", "count(d_year)"]
+        lines += ["sql SET threads TO 1", "sql PRAGMA enable_polr",
+                  "query q SELECT %s FROM lineorder JOIN date ON lo_orderdate = d_datekey WHERE %s" %
+                  (", ".join(exprs), wl["sql_where"]),
+                  "query f SELECT count(*) FROM lineorder WHERE lo_discount >= 1 AND lo_discount <= 3 AND lo_quantity < 25"]
+        script = os.path.join(workdir, "s.txt")
+        open(script, "w").write("\n".join(lines) + "\n")
+        outdir = os.path.join(workdir, "out")
+        proc = subprocess.run([mg.DRIVER, script, outdir], capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(proc.stdout + proc.stderr)
+        vals = [int(v) for v in open(os.path.join(outdir, "q.csv")).read().strip().splitlines()[1].split(",")]
+        n_filtered = int(open(os.path.join(outdir, "f.csv")).read().strip().splitlines()[1])
+        gold = {"exprs": exprs, "values": vals, "filtered_rows": n_filtered}
+        json.dump(gold, open(os.path.join(HERE, "ssb_q11.json"), "w"), indent=1)
+        print("ssb_q11", gold)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
 
 
 def main():
+    make_ssb_q11()
     gold = {}
     for name, make in mg.SCENARIOS.items():
         wl = make()

@@ -125,3 +125,65 @@ def test_device_aggregates_wide_values_and_nulls(gpu_ctx):
         out.aggregate([("sum", 0, 9)])
     pipe.close()
     ht.close()
+
+
+# ---- BASELINE configs[0]: SSB Q1.1 shape, end to end (source scan filter -> join -> aggregate sink) -------------
+Q11 = json.load(open(os.path.join(common.GOLDEN, "ssb_q11.json")))
+Q11_AGGS = [("count_star", None), ("sum", "lo_extendedprice"), ("min", "lo_extendedprice"), ("max", "lo_extendedprice"),
+            ("max", "lo_quantity"), ("min", "lo_discount"), ("sum", "lo_discount"), ("sum", "d_year"), ("count", "d_year")]
+
+
+def test_oracle_ssb_q11_matches_reference():
+    """filtered scan (oracle scan_filter) -> join (oracle pipeline) -> aggregates = the reference's answers"""
+    wl = workloads.ssb_q11()
+    names = list(wl["probe"]["cols"].keys())
+    cols = list(wl["probe"]["cols"].values())
+    flt = [(names.index(c), op, v) for c, op, v in wl["probe"]["filter"]]
+    sel, offs = orc.scan_filter(cols, flt)
+    assert len(sel) == Q11["filtered_rows"]
+    pcols, pvalid, joins = common.oracle_joins(wl)
+    res = orc.run_pipeline(pcols, joins, [[0]], routing="default_path", sel=sel, chunk_offsets=offs)
+    rows = res["out_rows"]
+    got = []
+    for fn, cname in Q11_AGGS:
+        if fn == "count_star":
+            got.append(len(rows))
+            continue
+        if cname in wl["probe"]["cols"]:
+            data, v = orc.materialize_column(rows, 1, -1, wl["probe"]["cols"][cname], None)
+        else:
+            data, v = orc.materialize_column(rows, 1, 0, wl["joins"][0]["payload"][cname], None)
+        got.append(exact(data, v)[fn])
+    assert got == Q11["values"]
+
+
+@pytest.mark.gpu
+def test_device_ssb_q11_matches_reference(gpu_ctx):
+    """the same query on the device: polr_pipeline_scan_filter -> resident run -> polr_out_aggregate; only the
+    nine aggregate values leave the GPU"""
+    from polr_amd import capi
+    wl = workloads.ssb_q11()
+    names = list(wl["probe"]["cols"].keys())
+    cols = list(wl["probe"]["cols"].values())
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, [[0]])
+    n_sel, n_chunks = pipe.scan_filter([(names.index(c), op, v) for c, op, v in wl["probe"]["filter"]])
+    assert n_sel == Q11["filtered_rows"]
+    out = capi.Output(pipe, 1024, 8192)
+    mpx = capi.DeviceMultiplexer(pipe, "default_path")
+    mpx.use_scan_chunks()
+    capi.run_resident([mpx], [(0, n_chunks)], out=out, reset=True, finish=True)
+    st = mpx.finish()
+    assert st["stage_out"][0][0] == Q11["values"][0]
+    specs = []
+    for fn, cname in Q11_AGGS:
+        if fn == "count_star":
+            specs.append((fn, -1, 0))
+        elif cname in wl["probe"]["cols"]:
+            specs.append((fn, -1, names.index(cname)))
+        else:
+            specs.append((fn, 0, list(wl["joins"][0]["payload"].keys()).index(cname)))
+    got = out.aggregate(specs[:8]) + out.aggregate(specs[8:])
+    assert got == Q11["values"]
+    mpx.close()
+    pipe.close()
