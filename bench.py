@@ -78,6 +78,8 @@ def build_workload(name, scale, seed):
     from polr_amd import workloads
     if name == "job_light_01":
         return workloads.job_light_01(scale=scale, seed=seed)
+    if name == "job_q18":
+        return workloads.job_q18(scale=scale, seed=seed)
     if name == "ssb_skew_q41":
         return workloads.ssb_skew_q41(sf=scale, seed=seed)
     if name == "star_skew":
@@ -220,7 +222,19 @@ def main():
     wl = wl0 if rank == 0 else build_workload(args.workload, args.scale,
                                               pdist.probe_partition_seed(workloads.SEED, rank))
     k = len(wl0["joins"])
-    paths = workloads.default_paths(k, "each_last_once")[:max(1, args.max_join_orders)]
+    if "cond_left_index" in wl0:
+        # joins keyed by build columns of earlier joins: the join orders come from the host mirror of
+        # POLARConfig::GenerateJoinOrders (dependencies respected), as they would inside the engine
+        from polr_amd import host as phost
+        gen = phost.generate_join_orders("each_last_once", len(wl0["probe"]["cols"]),
+                                         [len(j["payload"]) for j in wl0["joins"]], wl0["cond_left_index"],
+                                         [len(j["keys"][0]) for j in wl0["joins"]],
+                                         max_join_orders=max(1, args.max_join_orders), routing=args.routing)
+        if gen is None:
+            raise SystemExit("POLAR does not apply to this pipeline")
+        paths = gen[0]
+    else:
+        paths = workloads.default_paths(k, "each_last_once")[:max(1, args.max_join_orders)]
 
     # build sides: rank 0 builds in HBM, everyone else receives them over RCCL (one broadcast per buffer)
     joins = []

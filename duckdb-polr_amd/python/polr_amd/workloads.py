@@ -188,6 +188,68 @@ def job_light_01(scale=1.0, seed=SEED):
     return {"name": "job_light_01", "probe": probe, "joins": [jt, jmi], "ref": ref}
 
 
+def job_q18(scale=1.0, seed=SEED):
+    """JOB 18a shape (7 tables; the query BASELINE.json's >= 10x target is quoted on) at IMDB cardinalities:
+
+        cast_info ci (probe, filtered on note)  JOIN name n ON ci.person_id = n.id            (n filtered: ~0.5 %)
+                                                JOIN title t ON ci.movie_id = t.id
+                                                JOIN movie_info mi ON ci.movie_id = mi.movie_id   (fan-out ~6)
+                                                JOIN info_type it1 ON mi.info_type_id = it1.id    (DEPENDENT on mi; 1 row)
+                                                JOIN movie_info_idx mi_idx ON ci.movie_id = mi_idx.movie_id
+                                                JOIN info_type it2 ON mi_idx.info_type_id = it2.id (DEPENDENT on mi_idx)
+
+    six multiplexed joins, two of them keyed by a build column of an earlier join; COUNT(*) sink.  Strings (ci.note IN
+    (...), n.name LIKE, it.info = ...) are integer codes here: the filters are evaluated where the reference pushes
+    them (table scans), the joins see the same cardinalities."""
+    rng = _rng(seed, 18)
+    n_t = max(int(JOB_CARD["title"] * scale), 1000)
+    n_ci = max(int(JOB_CARD["cast_info"] * scale), 5000)
+    n_n = max(int(JOB_CARD["name"] * scale), 1000)
+    n_mi = max(int(JOB_CARD["movie_info"] * scale), 3000)
+    n_mx = max(int(JOB_CARD["movie_info_idx"] * scale), 1000)
+    ci = {"person_id": (zipf_keys(rng, n_ci, n_n, 0.8) + 1).astype(np.int32),
+          "movie_id": (zipf_keys(rng, n_ci, n_t, 0.9) + 1).astype(np.int32),
+          "note_id": rng.integers(0, 20, n_ci).astype(np.int32)}
+    n_id = np.arange(1, n_n + 1, dtype=np.int32)
+    n_flag = (rng.random(n_n) < 0.005).astype(np.int32)  # gender = 'm' AND name LIKE '%Tim%'
+    t_id = np.arange(1, n_t + 1, dtype=np.int32)[rng.permutation(n_t)]
+    mi_movie = (zipf_keys(rng, n_mi, n_t, 0.6) + 1).astype(np.int32)
+    mi_type = rng.integers(1, 21, n_mi).astype(np.int32)
+    mx_movie = (zipf_keys(rng, n_mx, n_t, 0.6) + 1).astype(np.int32)
+    mx_type = rng.integers(99, 114, n_mx).astype(np.int32)
+    it_id = np.arange(1, 114, dtype=np.int32)
+    it_code = it_id.copy()  # info_type.info as a code: 'budget' = 5, 'votes' = 112
+    jn = {"name": "name", "keys": [n_id[n_flag == 1]], "key_names": ["id"], "payload": {}, "key_src": [(-1, 0)],
+          "perfect": None}
+    jt = {"name": "title", "keys": [t_id], "key_names": ["id"], "payload": {}, "key_src": [(-1, 1)], "perfect": None}
+    jmi = {"name": "movie_info", "keys": [mi_movie], "key_names": ["movie_id"], "payload": {"info_type_id": mi_type},
+           "key_src": [(-1, 1)], "perfect": None}
+    jit1 = {"name": "info_type1", "keys": [it_id[it_code == 5]], "key_names": ["id"], "payload": {},
+            "key_src": [(2, 0)], "perfect": None}
+    jmx = {"name": "movie_info_idx", "keys": [mx_movie], "key_names": ["movie_id"], "payload": {"info_type_id": mx_type},
+           "key_src": [(-1, 1)], "perfect": None}
+    jit2 = {"name": "info_type2", "keys": [it_id[it_code == 112]], "key_names": ["id"], "payload": {},
+            "key_src": [(4, 0)], "perfect": None}
+    ref = {"tables": {"cast_info": ci, "name": {"id": n_id, "flag": n_flag}, "title": {"id": t_id},
+                      "movie_info": {"movie_id": mi_movie, "info_type_id": mi_type},
+                      "movie_info_idx": {"movie_id": mx_movie, "info_type_id": mx_type},
+                      "info_type": {"id": it_id, "info": it_code}},
+           "settings": ["SET disabled_optimizers TO 'join_order'"],
+           "query": "SELECT COUNT(*) FROM cast_info ci JOIN name n ON ci.person_id = n.id "
+                    "JOIN title t ON ci.movie_id = t.id JOIN movie_info mi ON ci.movie_id = mi.movie_id "
+                    "JOIN info_type it1 ON mi.info_type_id = it1.id "
+                    "JOIN movie_info_idx mi_idx ON ci.movie_id = mi_idx.movie_id "
+                    "JOIN info_type it2 ON mi_idx.info_type_id = it2.id "
+                    "WHERE ci.note_id <= 1 AND n.flag = 1 AND it1.info = 5 AND it2.info = 112"}
+    return {"name": "job_q18",
+            "probe": {"name": "cast_info", "cols": ci, "filter": [("note_id", "<=", 1)],
+                      "filter_sel": np.nonzero(ci["note_id"] <= 1)[0].astype(np.uint32)},
+            "joins": [jn, jt, jmi, jit1, jmx, jit2], "ref": ref,
+            # the BoundReference index of every join's probe-side condition in the original column layout
+            # (3 probe columns, then each join's build columns): what POLARConfig::GenerateJoinOrders works on
+            "cond_left_index": [[0], [1], [1], [3], [1], [4]]}
+
+
 # -------------------------------------------------------------------------------------------------
 # SSB-skew Q4.1 shape (BASELINE.json configs[2]): lineorder x {customer, supplier, part, date}
 # with the selective dimension changing along lo_orderkey (benchmark/ssb-skew/init/load.sql:80-253,

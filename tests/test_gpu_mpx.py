@@ -213,3 +213,38 @@ def test_auto_indexed_tables_match_reference(gpu_ctx, name):
     assert common.rows_digest_from_columns(cols) == (g["rows_sha256"], g["n_rows"])
     mpx.close()
     pipe.close()
+
+
+@pytest.mark.parametrize("routing", ["adaptive_reinit", "dynamic", "init_once"])
+def test_job_q18_shape_with_dependent_joins(gpu_ctx, routing):
+    """JOB 18a shape at scale 0.02: six multiplexed joins, two keyed by a build column of an earlier join, join
+    orders from the host mirror of GenerateJoinOrders, filtered source -- device (resident launch) vs oracle:
+    same routing trace, same totals, same COUNT(*)"""
+    from polr_amd import host
+    wl = workloads.job_q18(scale=0.02)
+    gen = host.generate_join_orders("each_last_once", len(wl["probe"]["cols"]),
+                                    [len(j["payload"]) for j in wl["joins"]], wl["cond_left_index"],
+                                    [len(j["keys"][0]) for j in wl["joins"]])
+    paths = gen[0]
+    assert len(paths) == 4 and gen[2][3][2] == 1 and gen[2][5][4] == 1  # it1 after mi, it2 after mi_idx
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    names = list(wl["probe"]["cols"].keys())
+    osel, ooffs = orc.scan_filter(pcols, [(names.index(c), op, v) for c, op, v in wl["probe"]["filter"]])
+    ref = orc.run_pipeline(pcols, ojoins, paths, routing=routing, caching=False, collect_output=False, sel=osel,
+                           chunk_offsets=ooffs)
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    pipe = capi.Pipeline(gpu_ctx, pcols, len(pcols[0]), joins, paths)
+    n_sel, n_chunks = pipe.scan_filter([(names.index(c), op, v) for c, op, v in wl["probe"]["filter"]])
+    assert n_sel == len(osel) and n_chunks == len(ooffs) - 1
+    mpx = capi.DeviceMultiplexer(pipe, routing)
+    mpx.use_scan_chunks()
+    capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+    st = mpx.finish()
+    _, _, inter = mpx.fetch_log()
+    assert list(inter) == list(ref["intermediates_per_round"])
+    assert st["num_intermediates"] == ref["num_intermediates"]
+    assert st["input_tuple_count_per_path"] == ref["input_tuple_count_per_path"][:len(paths)]
+    k = len(wl["joins"])
+    assert sum(st["stage_out"][p][k - 1] for p in range(len(paths))) == ref["num_output_rows"]
+    mpx.close()
+    pipe.close()
