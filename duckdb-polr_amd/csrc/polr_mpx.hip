@@ -2,17 +2,20 @@
 //
 // The reference asks its multiplexer for a route once per 1024-tuple chunk on the host
 // (POLARPipelineExecutor::Execute, src/parallel/polar_pipeline_executor.cpp:320-366).  Here the
-// multiplexer state (PhysicalMultiplexer + RoutingStrategy, polr_routing.h) lives in HBM and a
-// one-thread *router kernel* runs between two launches of the path kernel:
+// multiplexer state (PhysicalMultiplexer + RoutingStrategy, polr_routing.h) lives on the device and one
+// *routing step* (polr_mpx_device.h) runs between two probe rounds:
 //
-//     router: absorb the k counters of the previous round (AddNumIntermediates), FinalizePathRun,
-//             Route the next slice, fold the strategy's routing window (num_cache_flushing_skips whole
-//             chunks that bypass routing, :322-329) into the same round, write the round descriptor
-//     path kernel: probe that round, bump the counters
+//     absorb the k counters of the previous round (AddNumIntermediates), FinalizePathRun, Route the next slice,
+//     fold the strategy's routing window (num_cache_flushing_skips whole chunks that bypass routing, :322-329)
+//     into the same round, publish the round
 //
-// so a whole morsel is routed with zero host round trips; the host only polls a `done` word once per
-// batch of launches.  Output row sets and per-round intermediates equal the host classes' exactly:
-// same code (polr_routing.h), same IEEE double arithmetic.
+// Two ways to drive it, same decisions, same results (this file is their host side):
+//   * polr_mpx_run / _run_many: one launch of the path kernel per round; its last busy workgroup runs the step
+//     for the next round; the host pumps launches, throttled by two pinned progress words;
+//   * polr_mpx_run_resident: the whole run is one launch; per executor a router wave keeps the state in LDS
+//     and probe workgroups wait for its rounds on the device.
+// Output row sets and per-round intermediates equal the host classes' exactly: same code (polr_routing.h), same
+// IEEE double arithmetic.
 #include <stdlib.h>
 #include <string.h>
 
@@ -46,7 +49,6 @@ struct polr_mpx {
 	hipStream_t own_stream = nullptr;  // used when the caller passes no stream
 	hipStream_t last_stream = nullptr; // where the queued tail of the last run sits
 	uint32_t unit_size = 256;
-	int poll_batch = 8;
 	uint32_t wide0_mask = 0;
 	uint64_t n_chunks = 0;
 	// resident launches

@@ -1,6 +1,6 @@
 // duckdb-polr_amd/csrc/polr_routing.h -- the multiplexer's routing core, compiled for BOTH sides:
 // the C++ host mirror (duckdb-polr_amd/host: PhysicalMultiplexer / RoutingStrategy classes) and the
-// device router kernel (polr_mpx.hip).  One source => host and device decisions are the same double
+// device routing step (polr_mpx_device.h).  One source => host and device decisions are the same double
 // arithmetic (IEEE add/mul/div/round, compiled with -ffp-contract=off on both sides).
 //
 // Reference semantics (file:line in d-justen/duckdb-polr):

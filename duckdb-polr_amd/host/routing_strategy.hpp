@@ -1,7 +1,7 @@
 // duckdb-polr_amd/host/routing_strategy.hpp -- host mirror of the reference's RoutingStrategy family
 // (src/include/duckdb/execution/operator/polr/routing_strategy.hpp:15-213,
 //  src/execution/operator/polr/routing_strategy.cpp:7-463).  Same class names and the same Route()
-// contract; the arithmetic lives in csrc/polr_routing.h so that the device router kernel and these
+// contract; the arithmetic lives in csrc/polr_routing.h so that the device routing step and these
 // classes are one implementation.
 #pragma once
 

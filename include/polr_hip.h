@@ -265,9 +265,10 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 /* ---------------------------------------------------------------------------------------------
  * Device-resident multiplexer: PhysicalMultiplexer + RoutingStrategy + the reward update
  * (src/execution/operator/polr/physical_multiplexer.cpp:100-184, routing_strategy.cpp:7-463)
- * evaluated by a one-thread router kernel between probe launches, so a whole morsel is routed
- * without a host round trip per routing decision.  Decisions are bit-identical to the host
- * classes in duckdb-polr_amd/host (same double arithmetic, no contraction).
+ * evaluated on the device between probe rounds -- by the last workgroup of a path-kernel launch
+ * (polr_mpx_run, _run_many) or by the router wave of a resident launch (polr_mpx_run_resident) -- so a
+ * whole morsel is routed without a host round trip per routing decision.  Decisions are bit-identical
+ * to the host classes in duckdb-polr_amd/host (same source, same double arithmetic, no contraction).
  * ------------------------------------------------------------------------------------------- */
 typedef struct polr_mpx_config {
 	uint32_t routing;
