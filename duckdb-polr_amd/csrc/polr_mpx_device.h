@@ -551,7 +551,7 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 	bool have_spec = false;      // the round after it is published too (speculated), descriptor kept for the check
 	unsigned long long spec_bw = 0;
 	uint32_t spec_count = 0, spec_blocks = 0;
-	bool failed = false, finished = false;
+	bool failed = false;
 	while (true) {
 		__builtin_amdgcn_wave_barrier();
 		if (lane == 0) {
@@ -665,7 +665,6 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 					round_no = polr_res_next_round(round_no);
 					__hip_atomic_store(&x.sync->pub[lane].a[n_pub & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
 					                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					finished = true;
 					stop = true;
 				}
 				break; // (a rehearsal that runs off the end of the source publishes nothing)
