@@ -120,6 +120,7 @@ extern "C++" void polr_launch_reduce_counts(hipStream_t stream, const unsigned l
 	                                         SelfRoute sr);
 DECL_K(2)
 DECL_K(4)
+DECL_K(6)
 DECL_K(8)
 #define DECL_RES_K(KK)                                                                                                 \
 	int polr_resident_occupancy_k##KK(uint32_t W, uint32_t waves_per_block);                                          \
@@ -128,10 +129,11 @@ DECL_K(8)
 	                                             const ResidentExec *execs, uint32_t n_exec, DevOut out);
 DECL_RES_K(2)
 DECL_RES_K(4)
+DECL_RES_K(6)
 DECL_RES_K(8)
 
 static uint32_t compiled_k(uint32_t k) {
-	return k <= 2 ? 2 : (k <= 4 ? 4 : 8);
+	return k <= 2 ? 2 : (k <= 4 ? 4 : (k <= 6 ? 6 : 8));
 }
 
 extern "C++" size_t polr_path_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_per_block) {
@@ -140,6 +142,8 @@ extern "C++" size_t polr_path_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_p
 		return polr_path_lds_bytes_k2(W, waves_per_block);
 	case 4:
 		return polr_path_lds_bytes_k4(W, waves_per_block);
+	case 6:
+		return polr_path_lds_bytes_k6(W, waves_per_block);
 	default:
 		return polr_path_lds_bytes_k8(W, waves_per_block);
 	}
@@ -151,6 +155,8 @@ extern "C++" int polr_path_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_
 		return polr_path_occupancy_k2(W, waves_per_block);
 	case 4:
 		return polr_path_occupancy_k4(W, waves_per_block);
+	case 6:
+		return polr_path_occupancy_k6(W, waves_per_block);
 	default:
 		return polr_path_occupancy_k8(W, waves_per_block);
 	}
@@ -168,6 +174,9 @@ extern "C++" hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t
 	case 4:
 		return polr_launch_path_kernel_k4(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
 		                                  unit_sizes, out, counts, sr);
+	case 6:
+		return polr_launch_path_kernel_k6(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
+		                                  unit_sizes, out, counts, sr);
 	default:
 		return polr_launch_path_kernel_k8(W, n_blocks, waves_per_block, stream, pipe, rounds, unit_prefix, n_rounds,
 		                                  unit_sizes, out, counts, sr);
@@ -180,6 +189,8 @@ extern "C++" int polr_resident_occupancy(uint32_t k, uint32_t W, uint32_t waves_
 		return polr_resident_occupancy_k2(W, waves_per_block);
 	case 4:
 		return polr_resident_occupancy_k4(W, waves_per_block);
+	case 6:
+		return polr_resident_occupancy_k6(W, waves_per_block);
 	default:
 		return polr_resident_occupancy_k8(W, waves_per_block);
 	}
@@ -193,6 +204,8 @@ extern "C++" hipError_t polr_launch_resident_kernel(uint32_t W, uint32_t k, uint
 		return polr_launch_resident_kernel_k2(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
 	case 4:
 		return polr_launch_resident_kernel_k4(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
+	case 6:
+		return polr_launch_resident_kernel_k6(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
 	default:
 		return polr_launch_resident_kernel_k8(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
 	}

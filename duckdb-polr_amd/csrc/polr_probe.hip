@@ -54,9 +54,14 @@ __device__ __host__ constexpr int qtotal() {
 }
 // dwords of LDS one wave owns: descriptors, queues, narrow pending areas [K][64] x 2, pinned stage-0 rows
 // [256], wide pending areas [2][256] x 2
+// wide pending areas: stage 0 always, the last stage only where it takes wide steps (K <= 4, W <= 4)
+template <int W, int K>
+__device__ __host__ constexpr int wide_pend_slots() {
+	return (K <= 4 && W <= 4) ? 2 : 1;
+}
 template <int W, int K>
 __device__ __host__ constexpr int per_wave_dwords() {
-	return K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64 * WIDE + 2 * 64 * WIDE * 2;
+	return K * STAGE_DESC_DWORDS + qtotal<W, K>() + K * 64 * 2 + 64 * WIDE + wide_pend_slots<W, K>() * 64 * WIDE * 2;
 }
 #define NO_CHUNK 0xFFFFFFFFu
 
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	c.pend_pref = c.pend_start + K * 64;
 	c.batch0 = c.pend_pref + K * 64;
 	c.wpend_start = c.batch0 + 64 * WIDE;
-	c.wpend_pref = c.wpend_start + 2 * 64 * WIDE;
+	c.wpend_pref = c.wpend_start + wide_pend_slots<W, K>() * 64 * WIDE;
 #pragma unroll
 	for (int p = 0; p < K; p++) {
 		c.qsize[p] = c.pend_T[p] = c.pend_cur[p] = c.pend_base[p] = c.cnt[p] = 0;
@@ -1155,7 +1160,7 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 	c.pend_pref = c.pend_start + K * 64;
 	c.batch0 = c.pend_pref + K * 64;
 	c.wpend_start = c.batch0 + 64 * WIDE;
-	c.wpend_pref = c.wpend_start + 2 * 64 * WIDE;
+	c.wpend_pref = c.wpend_start + wide_pend_slots<W, K>() * 64 * WIDE;
 #pragma unroll
 	for (int p = 0; p < K; p++) {
 		c.qsize[p] = c.pend_T[p] = c.pend_cur[p] = c.pend_base[p] = c.cnt[p] = 0;
@@ -1264,7 +1269,8 @@ __global__ __launch_bounds__(256) void polr_path_kernel(const DevPipeline *__res
 
 static size_t lds_bytes_k(uint32_t W, uint32_t waves_per_block) {
 	const size_t queues = POLR_K <= 1 ? 0 : (size_t)W * QCAP1 + (size_t)(POLR_K - 2) * W * QCAPN;
-	return (size_t)waves_per_block * ((size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64 * WIDE + 2 * 64 * WIDE * 2) *
+	const size_t wslots = (POLR_K <= 4 && W <= 4) ? 2 : 1; // (wide_pend_slots<W, K>())
+	return (size_t)waves_per_block * ((size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64 * WIDE + wslots * 64 * WIDE * 2) *
 	           sizeof(uint32_t) +
 	       64; // + the static arrival flag of a self-routing launch
 }
