@@ -933,7 +933,6 @@ template <int W, int K>
 __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline *__restrict__ pipe,
                                                                ResidentExec *execs, uint32_t n_exec, DevOut out) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	__shared__ __attribute__((aligned(16))) uint32_t router_lds[POLR_RES_ROUTER_DWORDS];
 	__shared__ unsigned long long bcast[2][2];
 	__shared__ uint32_t bcast_slot[2];
 	const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -960,10 +959,15 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 	if (b == 0) {
 		if (wave_in_block == 0) {
 			const uint32_t dyn_dwords = wpb * per_wave_dwords<W, K>();
-			// the router workgroup's dynamic LDS: [chunk-offset window | copy of the state for speculation]
+			// the router workgroup's dynamic LDS (its probe waves are not used):
+			//   [multiplexer state + round scratch | chunk-offset window | saved state of a rehearsal]
+			// (static LDS would be charged to every workgroup and costs the K = 4 kernels their fourth
+			// workgroup per CU)
+			const uint32_t state_dwords = (POLR_RES_ROUTER_DWORDS + 3u) & ~3u;
 			const uint32_t scratch_dwords = (POLR_RES_HOT_DWORDS + 1u) & ~1u;
-			polr_resident_router(x, k, &execs[e].registered, wpb, threadIdx.x & 63, router_lds, (uint64_t *)lds,
-			                     (dyn_dwords - scratch_dwords) / 2, lds + (dyn_dwords - scratch_dwords));
+			polr_resident_router(x, k, &execs[e].registered, wpb, threadIdx.x & 63, lds,
+			                     (uint64_t *)(lds + state_dwords), (dyn_dwords - state_dwords - scratch_dwords) / 2,
+			                     lds + (dyn_dwords - scratch_dwords));
 		}
 		return;
 	}
