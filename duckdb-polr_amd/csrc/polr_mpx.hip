@@ -274,6 +274,28 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 	return POLR_OK;
 }
 
+int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_info *info) {
+	if (!p || !info) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = p->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const bool mat = materialize != 0;
+	const DevPipeline &dp = mat ? p->host_mat : p->host_count;
+	const uint32_t wpb = polr_waves_per_block(p, mat);
+	if (wpb == 0) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
+	}
+	memset(info, 0, sizeof(*info));
+	info->waves_per_workgroup = wpb;
+	info->workgroups_per_cu = (uint32_t)std::max(0, std::min(polr_resident_occupancy(dp.k, dp.W, wpb), 8));
+	info->lds_bytes_per_workgroup = (uint32_t)polr_path_lds_bytes(dp.k, dp.W, wpb);
+	info->compiled_stages = dp.k <= 2 ? 2 : (dp.k <= 4 ? 4 : (dp.k <= 6 ? 6 : 8));
+	info->tuple_slots = dp.W;
+	info->n_cus = (uint32_t)ctx->n_cus;
+	return POLR_OK;
+}
+
 // the source chunks are the ones polr_pipeline_scan_filter produced (boundaries stay on the device)
 int polr_mpx_use_scan_chunks(polr_mpx *m) {
 	if (!m) {

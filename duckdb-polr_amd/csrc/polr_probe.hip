@@ -1275,8 +1275,7 @@ static size_t lds_bytes_k(uint32_t W, uint32_t waves_per_block) {
 	const size_t queues = POLR_K <= 1 ? 0 : (size_t)W * QCAP1 + (size_t)(POLR_K - 2) * W * QCAPN;
 	const size_t wslots = (POLR_K <= 4 && W <= 4) ? 2 : 1; // (wide_pend_slots<W, K>())
 	return (size_t)waves_per_block * ((size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64 * WIDE + wslots * 64 * WIDE * 2) *
-	           sizeof(uint32_t) +
-	       64; // + the static arrival flag of a self-routing launch
+	       sizeof(uint32_t); // (the kernels' few static __shared__ words are accounted by the compiler)
 }
 
 #ifndef POLR_RESIDENT_KERNEL

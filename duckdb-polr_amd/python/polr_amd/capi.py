@@ -30,7 +30,7 @@ EXPORTS = [
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
-    "polr_ht_finalize_auto", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate",
+    "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate",
 ]
 
 
@@ -70,6 +70,11 @@ class AggValue(C.Structure):
 
 
 AGG = {"count_star": 0, "count": 1, "sum": 2, "min": 3, "max": 4}
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("waves_per_workgroup", "workgroups_per_cu", "lds_bytes_per_workgroup",
+                                          "compiled_stages", "tuple_slots", "n_cus")]
 
 
 class HtInfo(C.Structure):
@@ -144,6 +149,7 @@ def load():
     L.polr_mpx_reset.argtypes = [vp, vp]
     L.polr_mpx_run_many.argtypes = [vp, vp, vp, vp, u32, vp]
     L.polr_mpx_finish_many.argtypes = [vp, u32, vp]
+    L.polr_pipeline_launch_info.argtypes = [vp, C.c_int, vp]
     L.polr_ht_finalize_auto.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
     L.polr_pipeline_scan_filter.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.polr_pipeline_fetch_scan.argtypes = [vp, vp, vp]
@@ -336,6 +342,11 @@ class Pipeline:
         else:
             sel = np.ascontiguousarray(sel, dtype=np.uint32)
             self.ctx.check(self.ctx.L.polr_pipeline_set_selection(self.h, sel.ctypes.data, len(sel), 0))
+
+    def launch_info(self, materialize=False):
+        i = LaunchInfo()
+        self.ctx.check(self.ctx.L.polr_pipeline_launch_info(self.h, int(materialize), C.byref(i)))
+        return {f[0]: getattr(i, f[0]) for f in LaunchInfo._fields_}
 
     def scan_filter(self, filters, vector_size=1024, stream=None):
         """polr_pipeline_scan_filter: filters = [(col, op, constant)] with op in CMP; the selection and the chunk

@@ -165,6 +165,13 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
  * chunks (DICTIONARY/sliced vectors, vector.hpp:36-140): sel[i] = probe-table row.  NULL resets
  * to "all rows".  flags: POLR_COL_DEVICE if sel is a device pointer. */
 int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t n_sel, uint32_t flags);
+/* How the probe kernels of this pipeline are launched (diagnostic): waves per workgroup, workgroups resident per
+ * CU (resident kernel), dynamic LDS bytes per workgroup, compiled stage count K and tuple slots W.
+ * materialize != 0: the variant that writes row ids (an `out` object is passed to the runs). */
+typedef struct polr_launch_info {
+	uint32_t waves_per_workgroup, workgroups_per_cu, lds_bytes_per_workgroup, compiled_stages, tuple_slots, n_cus;
+} polr_launch_info;
+int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_info *info);
 
 /* ---- source side on the device ---------------------------------------
  * PhysicalTableScan with pushed-down table filters: the table is scanned in vectors of `vector_size`
