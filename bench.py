@@ -153,8 +153,8 @@ def cpu_baseline(wl, routing, n_tuples, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="job_light_01")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--routing", default="adaptive_reinit")
