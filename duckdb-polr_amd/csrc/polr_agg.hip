@@ -232,3 +232,290 @@ int polr_out_aggregate(polr_out *o, void *stream, const polr_agg_spec *specs, ui
 }
 
 } // extern "C"
+
+// ---- grouped aggregate over small dense group domains (PhysicalPerfectHashAggregate's case:
+// src/execution/operator/aggregate/physical_perfecthash_aggregate.cpp -- every group column has a small known
+// [min, max] range, the group index is the mixed-radix number of the key offsets).  SSB Q4.x:
+// GROUP BY d_year, c_nation = 7 x 25 groups.
+// One accumulator cell per (group, aggregate): the sum is kept as two 64-bit limbs -- the sum of the values' low 32
+// bits and the sum of their (signed) high parts -- so that plain 64-bit atomic adds stay exact for up to 2^32 rows;
+// workgroups accumulate in LDS and flush their non-empty cells to the global table once.
+struct GroupCell {
+	unsigned long long lo32; // sum of (v & 0xFFFFFFFF)
+	long long hi32;          // sum of (v >> 32), arithmetic
+	long long mn, mx;
+	unsigned long long count;
+};
+
+struct DevGroupKey {
+	DevCol src;
+	uint32_t slot;
+	uint32_t n_values;
+	int64_t min_value;
+};
+
+#define POLR_MAX_GROUP_KEYS 3
+struct DevGroupSet {
+	DevGroupKey k[POLR_MAX_GROUP_KEYS];
+	uint32_t n;
+	uint32_t n_groups;
+};
+
+#define POLR_GROUP_LDS_CELLS 1024
+
+__device__ __forceinline__ void cell_add(GroupCell *c, long long v) {
+	atomicAdd(&c->lo32, (unsigned long long)((unsigned long long)v & 0xFFFFFFFFull));
+	atomicAdd((unsigned long long *)&c->hi32, (unsigned long long)(v >> 32));
+	atomicMin(&c->mn, v);
+	atomicMax(&c->mx, v);
+	atomicAdd(&c->count, 1ull);
+}
+
+__global__ __launch_bounds__(256) void polr_group_init_kernel(GroupCell *cells, uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		cells[i].lo32 = 0;
+		cells[i].hi32 = 0;
+		cells[i].mn = 0x7FFFFFFFFFFFFFFFll;
+		cells[i].mx = (long long)0x8000000000000000ull;
+		cells[i].count = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void polr_group_agg_kernel(DevOut out, uint32_t n_chunks, DevGroupSet groups,
+                                                             DevAggSet aggs, GroupCell *__restrict__ table,
+                                                             unsigned long long *__restrict__ dropped, int use_lds) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	GroupCell *local = (GroupCell *)lds_raw;
+	const uint32_t n_cells = groups.n_groups * aggs.n;
+	if (use_lds) {
+		for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x) {
+			local[i].lo32 = 0;
+			local[i].hi32 = 0;
+			local[i].mn = 0x7FFFFFFFFFFFFFFFll;
+			local[i].mx = (long long)0x8000000000000000ull;
+			local[i].count = 0;
+		}
+		__syncthreads();
+	}
+	GroupCell *dst = use_lds ? local : table;
+	unsigned long long my_dropped = 0;
+	for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const uint32_t n = out.chunk_count[chunk];
+		const uint64_t chunk_base = (uint64_t)chunk * out.chunk_capacity;
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+			// group index: mixed-radix number of the key offsets
+			uint64_t g = 0;
+			bool ok = true;
+			for (uint32_t q = 0; q < groups.n; q++) {
+				const DevGroupKey &gk = groups.k[q];
+				const uint32_t row = out.ids[(uint64_t)gk.slot * out.slot_stride + chunk_base + i];
+				if (gk.src.valid && !gk.src.valid[row]) {
+					ok = false;
+					break;
+				}
+				const long long v = agg_cell(gk.src, row);
+				const unsigned long long off = (unsigned long long)(v - gk.min_value);
+				if (off >= gk.n_values) {
+					ok = false;
+					break;
+				}
+				g = g * gk.n_values + off;
+			}
+			if (!ok) {
+				my_dropped++;
+				continue;
+			}
+			for (uint32_t a = 0; a < aggs.n; a++) {
+				const DevAgg &ag = aggs.a[a];
+				GroupCell *c = &dst[g * aggs.n + a];
+				if (ag.fn == POLR_AGG_COUNT_STAR) {
+					atomicAdd(&c->count, 1ull);
+					continue;
+				}
+				const uint32_t row = out.ids[(uint64_t)ag.slot * out.slot_stride + chunk_base + i];
+				if (ag.src.valid && !ag.src.valid[row]) {
+					continue;
+				}
+				cell_add(c, agg_cell(ag.src, row));
+			}
+		}
+	}
+	if (my_dropped) {
+		atomicAdd(dropped, my_dropped);
+	}
+	if (use_lds) {
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x) {
+			const GroupCell c = local[i];
+			if (c.count) {
+				atomicAdd(&table[i].lo32, c.lo32);
+				atomicAdd((unsigned long long *)&table[i].hi32, (unsigned long long)c.hi32);
+				atomicMin(&table[i].mn, c.mn);
+				atomicMax(&table[i].mx, c.mx);
+				atomicAdd(&table[i].count, c.count);
+			}
+		}
+	}
+}
+
+static int resolve_agg_col(polr_pipeline *p, int32_t src_join, uint32_t src_col, const OwnedCol **c, uint32_t *slot,
+                           const char *what, uint32_t idx) {
+	polr_ctx *ctx = p->ctx;
+	if (src_join < 0) {
+		if (src_col >= p->n_probe_cols) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "%s %u: probe column %u out of range", what, idx, src_col);
+		}
+		*c = &p->probe_cols[src_col];
+		*slot = 0;
+	} else {
+		if ((uint32_t)src_join >= p->k || src_col >= p->hts[src_join]->n_payload) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "%s %u: build column (%d,%u) out of range", what, idx, src_join, src_col);
+		}
+		const polr_ht *ht = p->hts[src_join];
+		*c = ht->kind == KIND_PERFECT ? &ht->pcols[src_col] : &ht->payload[src_col];
+		*slot = 1 + (uint32_t)src_join;
+	}
+	if ((*c)->width > 8 || ((*c)->width == 8 && !((*c)->flags & 1u))) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "%s %u: only integer columns of up to 8 bytes (signed if 8)", what, idx);
+	}
+	return POLR_OK;
+}
+
+extern "C" int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_group_key *keys, uint32_t n_keys,
+                                          const polr_agg_spec *specs, uint32_t n_aggs, polr_agg_value *results,
+                                          uint64_t n_groups, uint64_t *n_dropped) {
+	if (!o || !keys || !specs || !results || n_keys == 0 || n_aggs == 0) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = o->pipe;
+	polr_ctx *ctx = p->ctx;
+	if (n_keys > POLR_MAX_GROUP_KEYS || n_aggs > POLR_MAX_AGGS) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "at most %d group columns and %d aggregates", POLR_MAX_GROUP_KEYS, POLR_MAX_AGGS);
+	}
+	DevGroupSet gs;
+	memset(&gs, 0, sizeof(gs));
+	gs.n = n_keys;
+	uint64_t groups = 1;
+	for (uint32_t q = 0; q < n_keys; q++) {
+		const OwnedCol *c = nullptr;
+		uint32_t slot = 0;
+		int rc = resolve_agg_col(p, keys[q].src_join, keys[q].src_col, &c, &slot, "group column", q);
+		if (rc) {
+			return rc;
+		}
+		if (keys[q].n_values == 0) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "group column %u: empty domain", q);
+		}
+		groups *= keys[q].n_values;
+		if (groups > (1u << 20)) {
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "more than 2^20 groups: not a perfect-hash aggregate");
+		}
+		gs.k[q].src.data = c->data;
+		gs.k[q].src.valid = c->valid;
+		gs.k[q].src.width = c->width;
+		gs.k[q].src.flags = c->flags;
+		gs.k[q].slot = slot;
+		gs.k[q].n_values = keys[q].n_values;
+		gs.k[q].min_value = keys[q].min_value;
+	}
+	if (groups != n_groups) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "results hold %llu groups, the domains span %llu", (unsigned long long)n_groups,
+		          (unsigned long long)groups);
+	}
+	gs.n_groups = (uint32_t)groups;
+	DevAggSet as;
+	memset(&as, 0, sizeof(as));
+	as.n = n_aggs;
+	for (uint32_t a = 0; a < n_aggs; a++) {
+		if (specs[a].fn > POLR_AGG_MAX) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "aggregate %u: unknown function %u", a, specs[a].fn);
+		}
+		as.a[a].fn = specs[a].fn;
+		if (specs[a].fn == POLR_AGG_COUNT_STAR) {
+			continue;
+		}
+		const OwnedCol *c = nullptr;
+		uint32_t slot = 0;
+		int rc = resolve_agg_col(p, specs[a].src_join, specs[a].src_col, &c, &slot, "aggregate", a);
+		if (rc) {
+			return rc;
+		}
+		as.a[a].src.data = c->data;
+		as.a[a].src.valid = c->valid;
+		as.a[a].src.width = c->width;
+		as.a[a].src.flags = c->flags;
+		as.a[a].slot = slot;
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	if (!o->stats_valid) {
+		int rc = polr_out_stats(o, stream, nullptr, nullptr, nullptr);
+		if (rc) {
+			return rc;
+		}
+	}
+	const uint32_t n_cells = (uint32_t)groups * n_aggs;
+	std::vector<GroupCell> host(n_cells);
+	unsigned long long h_dropped = 0;
+	GroupCell *table = nullptr;
+	unsigned long long *dropped = nullptr;
+	hipError_t e = hipMalloc((void **)&table, (size_t)n_cells * sizeof(GroupCell));
+	e = e == hipSuccess ? hipMalloc((void **)&dropped, 8) : e;
+	e = e == hipSuccess ? hipMemsetAsync(dropped, 0, 8, st) : e;
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(polr_group_init_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, table, n_cells);
+		if (o->n_chunks) {
+			const int use_lds = n_cells <= POLR_GROUP_LDS_CELLS;
+			const uint32_t n_blocks = std::max<uint32_t>(1, std::min<uint32_t>(o->n_chunks, (uint32_t)ctx->n_cus * 4));
+			hipLaunchKernelGGL(polr_group_agg_kernel, dim3(n_blocks), dim3(256),
+			                   use_lds ? (size_t)n_cells * sizeof(GroupCell) : 0, st, o->dev, o->n_chunks, gs, as, table,
+			                   dropped, use_lds);
+		}
+		e = hipMemcpyAsync(host.data(), table, (size_t)n_cells * sizeof(GroupCell), hipMemcpyDeviceToHost, st);
+		e = e == hipSuccess ? hipMemcpyAsync(&h_dropped, dropped, 8, hipMemcpyDeviceToHost, st) : e;
+		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+	}
+	if (table) {
+		hipFree(table);
+	}
+	if (dropped) {
+		hipFree(dropped);
+	}
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "grouped aggregate failed: %s", hipGetErrorString(e));
+	}
+	for (uint32_t i = 0; i < n_cells; i++) {
+		const GroupCell &c = host[i];
+		polr_agg_value &v = results[i];
+		memset(&v, 0, sizeof(v));
+		v.count = c.count;
+		const uint32_t fn = specs[i % n_aggs].fn;
+		const __int128 sum = ((__int128)c.hi32 << 32) + (__int128)c.lo32;
+		switch (fn) {
+		case POLR_AGG_COUNT_STAR:
+		case POLR_AGG_COUNT:
+			v.lo = (int64_t)c.count;
+			break;
+		case POLR_AGG_SUM:
+			v.is_null = c.count == 0;
+			v.lo = (int64_t)(unsigned long long)sum;
+			v.hi = (int64_t)(sum >> 64);
+			break;
+		case POLR_AGG_MIN:
+			v.is_null = c.count == 0;
+			v.lo = c.count ? c.mn : 0;
+			v.hi = (c.count && c.mn < 0) ? -1 : 0;
+			break;
+		default:
+			v.is_null = c.count == 0;
+			v.lo = c.count ? c.mx : 0;
+			v.hi = (c.count && c.mx < 0) ? -1 : 0;
+			break;
+		}
+	}
+	if (n_dropped) {
+		*n_dropped = h_dropped;
+	}
+	return POLR_OK;
+}

@@ -30,7 +30,7 @@ EXPORTS = [
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
-    "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate",
+    "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
 ]
 
 
@@ -75,6 +75,11 @@ AGG = {"count_star": 0, "count": 1, "sum": 2, "min": 3, "max": 4}
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("waves_per_workgroup", "workgroups_per_cu", "lds_bytes_per_workgroup",
                                           "compiled_stages", "tuple_slots", "n_cus")]
+
+
+class GroupKey(C.Structure):
+    _fields_ = [("src_join", C.c_int32), ("src_col", C.c_uint32), ("min_value", C.c_int64), ("n_values", C.c_uint32),
+                ("pad", C.c_uint32)]
 
 
 class HtInfo(C.Structure):
@@ -155,6 +160,7 @@ def load():
     L.polr_pipeline_fetch_scan.argtypes = [vp, vp, vp]
     L.polr_mpx_use_scan_chunks.argtypes = [vp]
     L.polr_out_aggregate.argtypes = [vp, vp, vp, u32, vp]
+    L.polr_out_aggregate_grouped.argtypes = [vp, vp, vp, u32, vp, u32, vp, C.c_uint64, vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
@@ -439,6 +445,27 @@ class Output:
         for r in res:
             out.append(None if r.is_null else (r.hi << 64) + (r.lo & 0xFFFFFFFFFFFFFFFF))
         return out
+
+    def aggregate_grouped(self, keys, specs, stream=None):
+        """polr_out_aggregate_grouped: keys = [(src_join, src_col, min, n_values)], specs as in aggregate() ->
+        (values[n_groups][n_aggs] of python int / None, counts[n_groups][n_aggs], n_dropped)"""
+        nk, na = len(keys), len(specs)
+        ka = (GroupKey * nk)()
+        n_groups = 1
+        for i, (sj, sc, mn, nv) in enumerate(keys):
+            ka[i].src_join, ka[i].src_col, ka[i].min_value, ka[i].n_values = sj, sc, int(mn), int(nv)
+            n_groups *= int(nv)
+        sa = (AggSpec * na)()
+        for i, (fn, sj, sc) in enumerate(specs):
+            sa[i].fn, sa[i].src_join, sa[i].src_col = AGG[fn] if isinstance(fn, str) else fn, sj, sc
+        res = (AggValue * (n_groups * na))()
+        dropped = C.c_uint64()
+        self.ctx.check(self.ctx.L.polr_out_aggregate_grouped(self.h, stream, ka, nk, sa, na, res, n_groups,
+                                                             C.byref(dropped)))
+        vals = [[None if res[g * na + a].is_null else (res[g * na + a].hi << 64) + (res[g * na + a].lo & 0xFFFFFFFFFFFFFFFF)
+                 for a in range(na)] for g in range(n_groups)]
+        counts = [[res[g * na + a].count for a in range(na)] for g in range(n_groups)]
+        return vals, counts, dropped.value
 
     def materialize(self, src_join, src_col, dtype, stream=None):
         n, _, _ = self.stats(stream)

@@ -245,6 +245,24 @@ typedef struct polr_agg_value {
 } polr_agg_value;
 int polr_out_aggregate(polr_out *o, void *stream, const polr_agg_spec *specs, uint32_t n_aggs,
                        polr_agg_value *results);
+/* The same aggregates GROUPed BY up to 3 integer columns with small dense domains -- the case the reference
+ * plans as PhysicalPerfectHashAggregate (src/execution/operator/aggregate/physical_perfecthash_aggregate.cpp:
+ * every group column has a known [min, max] from its statistics; SSB Q4.x: GROUP BY d_year, c_nation).  Group
+ * g = mixed-radix number of the key offsets, ((k0 - min0) * n1 + (k1 - min1)) * n2 + ...; results[g * n_aggs + a];
+ * a group no row fell into has count 0 (COUNT) / is_null (SUM, MIN, MAX) and is simply absent from the
+ * reference's result.  Rows whose group key is NULL or outside its domain are not aggregated; *n_dropped (may
+ * be NULL) counts them (the caller sizes the domains from the build columns' statistics, so normally 0).
+ * At most 2^20 groups. */
+typedef struct polr_group_key {
+	int32_t src_join;   /* -1 = probe-table column, j >= 0 = payload column of join j */
+	uint32_t src_col;
+	int64_t min_value;
+	uint32_t n_values;  /* max - min + 1 */
+	uint32_t pad;
+} polr_group_key;
+int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_group_key *keys, uint32_t n_keys,
+                               const polr_agg_spec *specs, uint32_t n_aggs, polr_agg_value *results,
+                               uint64_t n_groups, uint64_t *n_dropped);
 void polr_out_destroy(polr_out *o);
 
 /* ---------------------------------------------------------------------------------------------

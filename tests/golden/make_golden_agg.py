@@ -50,8 +50,46 @@ def make_ssb_q11():
         shutil.rmtree(workdir, ignore_errors=True)
 
 
+def make_ssb_q41_groups():
+    """SSB Q4.1's GROUP BY d_year, c_nation over the SSB-skew shaped star join (sf 0.2), from the reference with
+    POLAR enabled -> tests/golden/ssb_q41_groups.json.  sum(lo_revenue - lo_supplycost) is linear: the fixture
+    keeps both sums (and the reference's own value of the difference as a cross-check)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from polr_amd import workloads
+    wl = workloads.ssb_skew_q41(sf=0.2)
+    workdir = tempfile.mkdtemp(prefix="polr_golden_")
+    try:
+        lines = []
+        mg.table_script(lines, workdir, wl["probe"]["name"], wl["probe"]["cols"])
+        for j in wl["joins"]:
+            cols = {kn: kk for kn, kk in zip(j["key_names"], j["keys"])}
+            cols.update(j["payload"])
+            mg.table_script(lines, workdir, j["name"], cols)
+        select = ("d_year, c_nation, count(*), sum(lo_revenue), sum(lo_supplycost), min(lo_revenue), "
+                  "max(lo_supplycost), sum(CAST(lo_revenue AS BIGINT) - CAST(lo_supplycost AS BIGINT))")
+        query = mg.workload_sql(wl, select)[0] + " GROUP BY d_year, c_nation ORDER BY d_year, c_nation"
+        lines += ["sql SET threads TO 1", "sql SET disabled_optimizers TO 'join_order'", "sql PRAGMA enable_polr",
+                  "sql SET join_enumerator TO 'dfs_min_card'", "sql SET max_join_orders TO 3", "query q " + query]
+        script = os.path.join(workdir, "s.txt")
+        open(script, "w").write("\n".join(lines) + "\n")
+        outdir = os.path.join(workdir, "out")
+        proc = subprocess.run([mg.DRIVER, script, outdir], capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(proc.stdout + proc.stderr)
+        rows = [[int(v) for v in l.split(",")] for l in open(os.path.join(outdir, "q.csv")).read().strip().splitlines()[1:]]
+        gold = {"columns": ["d_year", "c_nation", "count_star", "sum_revenue", "sum_supplycost", "min_revenue",
+                            "max_supplycost", "sum_profit"], "rows": rows}
+        json.dump(gold, open(os.path.join(HERE, "ssb_q41_groups.json"), "w"))
+        print("ssb_q41_groups", len(rows), "groups", rows[0])
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+
+
 def main():
     make_ssb_q11()
+    make_ssb_q41_groups()
     gold = {}
     for name, make in mg.SCENARIOS.items():
         wl = make()

@@ -187,3 +187,78 @@ def test_device_ssb_q11_matches_reference(gpu_ctx):
     assert got == Q11["values"]
     mpx.close()
     pipe.close()
+
+
+# ---- grouped sink: SSB Q4.1's GROUP BY d_year, c_nation ------------------------------------------------------
+Q41 = json.load(open(os.path.join(common.GOLDEN, "ssb_q41_groups.json")))
+
+
+def _q41_want():
+    return {(r[0], r[1]): r[2:] for r in Q41["rows"]}
+
+
+def test_oracle_ssb_q41_groups_match_reference():
+    """oracle pipeline -> materialised columns -> python group-by = the reference's GROUP BY answer (175 groups)"""
+    wl = workloads.ssb_skew_q41(sf=0.2)
+    pcols, pvalid, joins = common.oracle_joins(wl)
+    k = len(joins)
+    res = orc.run_pipeline(pcols, joins, [list(range(k))], routing="default_path")
+    rows = res["out_rows"]
+    rev, _ = orc.materialize_column(rows, k, -1, wl["probe"]["cols"]["lo_revenue"], None)
+    sup, _ = orc.materialize_column(rows, k, -1, wl["probe"]["cols"]["lo_supplycost"], None)
+    nat, _ = orc.materialize_column(rows, k, 0, wl["joins"][0]["payload"]["c_nation"], None)
+    yr, _ = orc.materialize_column(rows, k, 3, wl["joins"][3]["payload"]["d_year"], None)
+    got = {}
+    for y, c, r, s in zip(yr.tolist(), nat.tolist(), rev.tolist(), sup.tolist()):
+        g = got.setdefault((y, c), [0, 0, 0, r, s, 0])
+        g[0] += 1
+        g[1] += r
+        g[2] += s
+        g[3] = min(g[3], r)
+        g[4] = max(g[4], s)
+        g[5] += r - s
+    assert got == _q41_want()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("routing", ["adaptive_reinit", "default_path"])
+def test_device_ssb_q41_groups_match_reference(gpu_ctx, routing):
+    """the SSB Q4.1 sink on the device: GROUP BY d_year, c_nation over the multiplexed star join's row-id output;
+    sum(lo_revenue - lo_supplycost) = sum(lo_revenue) - sum(lo_supplycost)"""
+    from polr_amd import capi
+    wl = workloads.ssb_skew_q41(sf=0.2)
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    names = list(wl["probe"]["cols"].keys())
+    n = len(cols[0])
+    paths = np.asarray(common.load_golden("ssb_skew_q41")["paths"], dtype=np.int32)
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    out = capi.Output(pipe, 1024, 8192)
+    mpx = capi.DeviceMultiplexer(pipe, routing)
+    capi.run_resident([mpx], [(0, (n + 1023) // 1024)], out=out, reset=True, finish=True)
+    mpx.finish()
+    years = sorted({r[0] for r in Q41["rows"]})
+    y0, ny = years[0], years[-1] - years[0] + 1
+    keys = [(3, 0, y0, ny), (0, 0, 0, 25)]  # d_year (payload 0 of join 3), c_nation (payload 0 of join 0)
+    specs = [("count_star", -1, 0), ("sum", -1, names.index("lo_revenue")), ("sum", -1, names.index("lo_supplycost")),
+             ("min", -1, names.index("lo_revenue")), ("max", -1, names.index("lo_supplycost"))]
+    vals, counts, dropped = out.aggregate_grouped(keys, specs)
+    assert dropped == 0
+    want = _q41_want()
+    seen = 0
+    for g, v in enumerate(vals):
+        key = (y0 + g // 25, g % 25)
+        if key in want:
+            w = want[key]
+            assert v == w[:5], key
+            assert v[1] - v[2] == w[5]  # the profit column of Q4.1
+            seen += 1
+        else:
+            assert v[0] == 0 and v[1] is None and v[3] is None  # an empty group: absent from the reference's result
+    assert seen == len(want)
+    # a domain that is too narrow drops rows instead of writing outside the table
+    vals2, _, dropped2 = out.aggregate_grouped([(3, 0, y0, 1), (0, 0, 0, 25)], specs[:1])
+    assert dropped2 == sum(r[2] for r in Q41["rows"] if r[0] != y0)
+    assert sum(v[0] for v in vals2) == sum(r[2] for r in Q41["rows"] if r[0] == y0)
+    mpx.close()
+    pipe.close()
