@@ -383,9 +383,9 @@ def main():
     for i in range(args.steps):
         step(fetch=not pipelined or i == args.steps - 1)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0  # this rank's K steps; the job's time is the MAX over ranks (below)
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
     st = merged(results)
     # ---- same K steps again with a HIP event pair around every path-kernel launch (on the launch
     # stream) to get the dominant kernel's device time for the roofline; the event records cost ~8 us of
