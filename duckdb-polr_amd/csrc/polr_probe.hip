@@ -40,6 +40,7 @@
 #define QCAP1 320
 #define QCAPN 128
 #define WIDE 4 // tuples per lane of a wide stage-0 step
+static_assert(64 * WIDE <= 256, "the pinned-step expansion searches 256 prefix entries in 8 halvings");
 template <int POS>
 __device__ __host__ constexpr int qcap() {
 	return POS == 1 ? QCAP1 : QCAPN;
