@@ -104,3 +104,35 @@ def test_device_executors_count_star(gpu_ctx, routing):
     for m in mpxs:
         m.close()
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("routing", ["alternate", "exponential_backoff", "init_once"])
+def test_many_rounds_published_ahead(gpu_ctx, routing):
+    """stress for the resident router's two round slots: 6 M tuples (sf 1.0), one executor -- ALTERNATE publishes
+    every one of its 17 580 rounds ahead of the previous round's counters, EXPONENTIAL_BACKOFF re-enters its init
+    phase hundreds of times; traces, totals and COUNT(*) against the oracle"""
+    from polr_amd import capi
+    wl = workloads.ssb_skew_q41(sf=1.0)
+    paths = np.asarray(GOLD["paths"], dtype=np.int32)
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    n = len(pcols[0])
+    ref = orc.run_pipeline(pcols, ojoins, paths, routing=routing, caching=False, collect_output=False,
+                           regret_budget=budget(routing, n))
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    pipe = capi.Pipeline(gpu_ctx, pcols, n, joins, paths)
+    mpx = capi.DeviceMultiplexer(pipe, routing, regret_budget=budget(routing, n), max_log_rounds=1 << 16)
+    capi.run_resident([mpx], [(0, (n + 1023) // 1024)], reset=True, finish=True)
+    st = mpx.finish()
+    _, _, inter = mpx.fetch_log()
+    k = len(wl["joins"])
+    if routing == "alternate":
+        assert np.array_equal(inter.reshape(-1, 3), ref["alt_matrix"])
+        assert st["stage_out"][0][k - 1] == ref["num_output_rows"]
+    else:
+        assert list(inter) == list(ref["intermediates_per_round"])
+        assert st["input_tuple_count_per_path"] == ref["input_tuple_count_per_path"][:3]
+        assert sum(st["stage_out"][p][k - 1] for p in range(3)) == ref["num_output_rows"]
+    assert st["num_intermediates"] == ref["num_intermediates"]
+    mpx.close()
+    pipe.close()
