@@ -248,3 +248,28 @@ def test_job_q18_shape_with_dependent_joins(gpu_ctx, routing):
     assert sum(st["stage_out"][p][k - 1] for p in range(len(paths))) == ref["num_output_rows"]
     mpx.close()
     pipe.close()
+
+
+def test_round_counter_wraps(gpu_ctx):
+    """more routing rounds in one resident run than the 20-bit round number of the device protocol holds:
+    ALTERNATE over 2-tuple chunks, 3 join orders, 350 000 chunks = 1 050 000 rounds (> 2^20); trace vs oracle"""
+    wl = workloads.star_skew(n_fact=700_000)
+    k = len(wl["joins"])
+    paths = workloads.default_paths(k, "each_last_once")
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    n = len(pcols[0])
+    ref = orc.run_pipeline(pcols, ojoins, paths, routing="alternate", caching=False, collect_output=False,
+                           vector_size=2)
+    joins = capi.build_joins(gpu_ctx, wl)
+    pipe = capi.Pipeline(gpu_ctx, pcols, n, joins, paths)
+    n_chunks = (n + 1) // 2
+    assert n_chunks * len(paths) > (1 << 20)
+    mpx = capi.DeviceMultiplexer(pipe, "alternate", chunk_size=2, max_log_rounds=n_chunks * len(paths) + 8)
+    capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+    st = mpx.finish()
+    _, tuples, inter = mpx.fetch_log()
+    assert len(inter) == n_chunks * len(paths)
+    assert np.array_equal(inter.reshape(-1, len(paths)), ref["alt_matrix"])
+    assert st["num_intermediates"] == ref["num_intermediates"]
+    mpx.close()
+    pipe.close()
