@@ -301,7 +301,7 @@ def main():
         scan_info = {"rows": n_rows, "selected": int(n_tuples), "chunks": int(n_chunks),
                      "ms": round(best * 1e3, 4), "algorithmic_bytes": int(scan_bytes),
                      "GB/s": round(scan_bytes / best / 1e9, 1),
-                     "note": "whole call incl. two synchronisations and the result allocation; outside the timed region"}
+                     "note": "whole call (five kernels, one synchronisation); outside the timed region"}
         if sel is not None and n_tuples != len(sel):
             raise SystemExit("device scan selected %d rows, the workload's host filter %d" % (n_tuples, len(sel)))
         offs = None

@@ -1108,11 +1108,8 @@ int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t 
 	}
 	p->sel_dev = nullptr;
 	p->sel_owned = false;
-	if (p->scan_offsets_dev) { // a caller-given selection replaces a scan result
-		hipFree(p->scan_offsets_dev);
-		p->scan_offsets_dev = nullptr;
-		p->scan_n_chunks = 0;
-	}
+	p->scan_n_chunks = 0; // a caller-given selection replaces a scan result (its buffers stay for the next scan)
+	p->scan_valid = false;
 	if (!sel) {
 		p->n_tuples = p->n_probe_rows;
 	} else {
@@ -1192,6 +1189,14 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	}
 	if (p->scan_offsets_dev) {
 		hipFree(p->scan_offsets_dev);
+	}
+	if (p->scan_sel) {
+		hipFree(p->scan_sel);
+	}
+	if (p->scan_packed) {
+		hipFree(p->scan_packed);
+		hipFree(p->scan_sums);
+		hipFree(p->scan_totals);
 	}
 	if (p->dev_mat) {
 		hipFree(p->dev_mat);

@@ -66,6 +66,12 @@ struct polr_pipeline {
 	uint64_t *scan_offsets_dev = nullptr;
 	uint64_t scan_n_chunks = 0;
 	uint32_t scan_vector_size = 0;
+	// scan buffers, sized for the worst case and reused by every polr_pipeline_scan_filter call
+	uint32_t *scan_sel = nullptr;
+	unsigned long long *scan_packed = nullptr, *scan_sums = nullptr, *scan_totals = nullptr;
+	uint64_t scan_cap_rows = 0, scan_cap_vec = 0;
+	bool scan_valid = false;      // a scan result is installed (selection + chunk boundaries)
+	uint64_t scan_generation = 0; // bumped by every scan: multiplexers must re-attach (polr_mpx_use_scan_chunks)
 	std::vector<polr_ht *> hts;
 	DevPipeline host_count, host_mat; // count-only (narrow tuples) and materialising (all ids) variants
 	DevPipeline *dev_count = nullptr, *dev_mat = nullptr;

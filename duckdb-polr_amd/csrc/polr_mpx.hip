@@ -39,7 +39,8 @@ struct polr_mpx {
 	uint32_t iter = 0; // launches of the path kernel so far (descriptor slot = iter & 1)
 	unsigned long long *counts_dev = nullptr;
 	uint64_t *chunk_offsets_dev = nullptr;
-	bool chunk_offsets_owned = true; // false: the pipeline's scan result
+	bool chunk_offsets_owned = true; // false: the pipeline's scan result ...
+	uint64_t scan_generation = 0;    // ... of this scan
 	uint32_t *log_path = nullptr;
 	uint64_t *log_tuples = nullptr, *log_inter = nullptr;
 	uint32_t *done_host = nullptr;        // pinned, mapped: [0] routing steps completed, [1] done
@@ -303,7 +304,7 @@ int polr_mpx_use_scan_chunks(polr_mpx *m) {
 	}
 	polr_pipeline *p = m->pipe;
 	polr_ctx *ctx = p->ctx;
-	if (!p->scan_offsets_dev) {
+	if (!p->scan_valid) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "no scan result: call polr_pipeline_scan_filter first");
 	}
 	if (m->chunk_offsets_dev && m->chunk_offsets_owned) {
@@ -312,6 +313,7 @@ int polr_mpx_use_scan_chunks(polr_mpx *m) {
 	}
 	m->chunk_offsets_dev = p->scan_offsets_dev;
 	m->chunk_offsets_owned = false;
+	m->scan_generation = p->scan_generation;
 	m->n_chunks = p->scan_n_chunks;
 	return POLR_OK;
 }
@@ -333,6 +335,9 @@ static int run_begin(RunState &rs, polr_mpx *m, void *stream, uint64_t chunk_beg
                      polr_out *out, uint32_t share) {
 	polr_pipeline *p = m->pipe;
 	polr_ctx *ctx = p->ctx;
+	if (!m->chunk_offsets_owned && (!p->scan_valid || m->scan_generation != p->scan_generation)) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "the pipeline was scanned again: call polr_mpx_use_scan_chunks");
+	}
 	if (chunk_begin > chunk_end || chunk_end > m->n_chunks) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks",
 		          (unsigned long long)chunk_begin, (unsigned long long)chunk_end, (unsigned long long)m->n_chunks);
@@ -514,6 +519,9 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 			if (ms[j] == ms[i]) {
 				POLR_FAIL(ctx, POLR_E_INVALID, "the same multiplexer twice in one resident run");
 			}
+		}
+		if (!ms[i]->chunk_offsets_owned && (!p->scan_valid || ms[i]->scan_generation != p->scan_generation)) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "the pipeline was scanned again: call polr_mpx_use_scan_chunks");
 		}
 		if (chunk_begin[i] > chunk_end[i] || chunk_end[i] > ms[i]->n_chunks) {
 			POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks",

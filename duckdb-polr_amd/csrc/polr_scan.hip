@@ -228,13 +228,13 @@ __global__ __launch_bounds__(256) void polr_tscan_write_kernel(DevFilterSet fs, 
                                                               uint64_t n_vec,
                                                               const unsigned long long *__restrict__ prefix,
                                                               uint32_t *__restrict__ sel,
-                                                              uint64_t *__restrict__ chunk_offsets, uint64_t n_sel,
-                                                              uint64_t n_chunks) {
+                                                              uint64_t *__restrict__ chunk_offsets,
+                                                              const unsigned long long *__restrict__ totals) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
 	if (wave == 0 && lane == 0) {
-		chunk_offsets[n_chunks] = n_sel;
+		chunk_offsets[totals[1]] = totals[0]; // the end of the last chunk
 	}
 	for (uint64_t v = wave; v < n_vec; v += n_waves) {
 		const unsigned long long pv = prefix[v];
@@ -310,15 +310,45 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 	if (n_vec >= (1ull << 23)) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "more than 2^23 scan vectors per partition");
 	}
-	// scratch: packed per-vector counts -> prefixes, block sums, totals
-	unsigned long long *packed = nullptr, *sums = nullptr, *totals = nullptr;
-	hipError_t e = hipMalloc((void **)&packed, std::max<uint64_t>(n_vec, 1) * 8);
-	e = e == hipSuccess ? hipMalloc((void **)&sums, std::max<uint64_t>(n_blocks, 1) * 8) : e;
-	e = e == hipSuccess ? hipMalloc((void **)&totals, 16) : e;
+	// Scratch and result buffers belong to the pipeline and are sized for the worst case (every row survives, every
+	// vector is a chunk), so the whole scan is enqueued without a host round trip in the middle; one
+	// synchronisation at the end reads the two totals.
+	if (p->scan_cap_rows < n_rows || p->scan_cap_vec < n_vec) {
+		if (p->scan_packed) {
+			hipFree(p->scan_packed);
+			hipFree(p->scan_sums);
+			hipFree(p->scan_totals);
+			p->scan_packed = p->scan_sums = p->scan_totals = nullptr;
+		}
+		if (p->scan_sel) {
+			if (p->sel_dev == p->scan_sel) {
+				p->sel_dev = nullptr;
+			}
+			hipFree(p->scan_sel);
+			p->scan_sel = nullptr;
+		}
+		if (p->scan_offsets_dev) {
+			hipFree(p->scan_offsets_dev);
+			p->scan_offsets_dev = nullptr;
+		}
+		hipError_t ea = hipMalloc((void **)&p->scan_packed, std::max<uint64_t>(n_vec, 1) * 8);
+		ea = ea == hipSuccess ? hipMalloc((void **)&p->scan_sums, std::max<uint64_t>(n_blocks, 1) * 8) : ea;
+		ea = ea == hipSuccess ? hipMalloc((void **)&p->scan_totals, 16) : ea;
+		ea = ea == hipSuccess ? hipMalloc((void **)&p->scan_sel, std::max<uint64_t>(n_rows, 1) * 4) : ea;
+		ea = ea == hipSuccess ? hipMalloc((void **)&p->scan_offsets_dev, (n_vec + 1) * 8) : ea;
+		if (ea != hipSuccess) {
+			p->scan_cap_rows = p->scan_cap_vec = 0;
+			POLR_FAIL(ctx, POLR_E_HIP, "scan filter buffers: %s", hipGetErrorString(ea));
+		}
+		p->scan_cap_rows = n_rows;
+		p->scan_cap_vec = n_vec;
+	}
+	unsigned long long *packed = p->scan_packed, *sums = p->scan_sums, *totals = p->scan_totals;
+	uint32_t *sel = p->scan_sel;
+	uint64_t *offs = p->scan_offsets_dev;
 	uint64_t h_tot[2] = {0, 0};
-	uint32_t *sel = nullptr;
-	uint64_t *offs = nullptr;
-	if (e == hipSuccess && n_vec) {
+	hipError_t e = hipSuccess;
+	if (n_vec) {
 		const uint32_t waves_per_block = 4;
 		const uint32_t grid = (uint32_t)std::min<uint64_t>((n_vec + waves_per_block - 1) / waves_per_block,
 		                                                   (uint64_t)ctx->n_cus * 8);
@@ -326,49 +356,26 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 		hipLaunchKernelGGL(polr_tscan_block_sums_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
 		hipLaunchKernelGGL(polr_tscan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, n_blocks, totals);
 		hipLaunchKernelGGL(polr_tscan_apply_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
+		hipLaunchKernelGGL(polr_tscan_write_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec, packed,
+		                   sel, offs, totals);
 		e = hipMemcpyAsync(h_tot, totals, 16, hipMemcpyDeviceToHost, st);
 		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
-		e = e == hipSuccess ? hipMalloc((void **)&sel, std::max<uint64_t>(h_tot[0], 1) * 4) : e;
-		e = e == hipSuccess ? hipMalloc((void **)&offs, (h_tot[1] + 1) * 8) : e;
-		if (e == hipSuccess) {
-			hipLaunchKernelGGL(polr_tscan_write_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec,
-			                   packed, sel, offs, h_tot[0], h_tot[1]);
-			e = hipStreamSynchronize(st);
-		}
-	} else if (e == hipSuccess) {
-		e = hipMalloc((void **)&sel, 4);
-		e = e == hipSuccess ? hipMalloc((void **)&offs, 8) : e;
-		e = e == hipSuccess ? hipMemset(offs, 0, 8) : e;
-	}
-	if (packed) {
-		hipFree(packed);
-	}
-	if (sums) {
-		hipFree(sums);
-	}
-	if (totals) {
-		hipFree(totals);
+	} else {
+		e = hipMemsetAsync(offs, 0, 8, st);
+		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
 	}
 	if (e != hipSuccess) {
-		if (sel) {
-			hipFree(sel);
-		}
-		if (offs) {
-			hipFree(offs);
-		}
 		POLR_FAIL(ctx, POLR_E_HIP, "scan filter failed: %s", hipGetErrorString(e));
 	}
-	// install: the selection is the pipeline's source now
-	if (p->sel_dev && p->sel_owned) {
+	// install: the selection is the pipeline's source now (the buffers stay the pipeline's scan buffers)
+	if (p->sel_dev && p->sel_owned && p->sel_dev != p->scan_sel) {
 		hipFree(p->sel_dev);
 	}
-	if (p->scan_offsets_dev) {
-		hipFree(p->scan_offsets_dev);
-	}
 	p->sel_dev = sel;
-	p->sel_owned = true;
+	p->sel_owned = false; // (freed as scan_sel)
 	p->n_tuples = h_tot[0];
-	p->scan_offsets_dev = offs;
+	p->scan_valid = true;
+	p->scan_generation++;
 	p->scan_n_chunks = h_tot[1];
 	p->scan_vector_size = vector_size;
 	p->host_mat.sel = p->sel_dev;
@@ -391,7 +398,7 @@ int polr_pipeline_fetch_scan(polr_pipeline *p, uint32_t *sel, uint64_t *chunk_of
 		return POLR_E_INVALID;
 	}
 	polr_ctx *ctx = p->ctx;
-	if (!p->scan_offsets_dev) {
+	if (!p->scan_valid) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "no scan result: call polr_pipeline_scan_filter first");
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -317,7 +317,8 @@ typedef struct polr_mpx_stats {
 } polr_mpx_stats;
 
 int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out);
-/* the source chunks are those of the pipeline's polr_pipeline_scan_filter result (boundaries stay in HBM) */
+/* the source chunks are those of the pipeline's polr_pipeline_scan_filter result (boundaries stay in HBM);
+ * to be called again after every new scan of the pipeline (a run with a stale attachment is POLR_E_INVALID) */
 int polr_mpx_use_scan_chunks(polr_mpx *m);
 /* Route and probe source chunks [chunk_begin, chunk_end) (chunk c = tuples [c*chunk_size, ...)
  * unless chunk offsets were set) entirely on the device; asynchronous. */
