@@ -2,49 +2,59 @@
 
 namespace duckdb_polr {
 
+namespace {
+
+// which path produced the chunk: pinned by the caller, else whatever the executor put in the thread context
+struct UnionState : public OperatorState {
+	explicit UnionState(vector<idx_t> *pinned_path_p) : pinned_path(pinned_path_p) {
+	}
+	vector<idx_t> *pinned_path;
+};
+
+} // namespace
+
 PhysicalAdaptiveUnion::PhysicalAdaptiveUnion(vector<LogicalType> types, idx_t num_columns_from_left_p,
                                              vector<idx_t> num_columns_per_join_p, idx_t estimated_cardinality)
     : PhysicalOperator(PhysicalOperatorType::ADAPTIVE_UNION, std::move(types), estimated_cardinality),
       num_columns_from_left(num_columns_from_left_p), num_columns_per_join(std::move(num_columns_per_join_p)) {
+	// cumulative widths -> (first column, width) of every join's build columns in the original layout
+	idx_t begin = num_columns_from_left;
+	for (idx_t end : num_columns_per_join) {
+		spans.push_back(ColumnSpan {begin, end - begin});
+		begin = end;
+	}
 }
 
-class AdaptiveUnionState : public OperatorState {
-public:
-	explicit AdaptiveUnionState(vector<idx_t> *input_join_order_p = nullptr) : input_join_order(input_join_order_p) {
-	}
-	vector<idx_t> *input_join_order;
-};
-
-unique_ptr<OperatorState> PhysicalAdaptiveUnion::GetOperatorState(ExecutionContext &context) const {
-	return unique_ptr<OperatorState>(new AdaptiveUnionState());
+unique_ptr<OperatorState> PhysicalAdaptiveUnion::GetOperatorState(ExecutionContext &) const {
+	return unique_ptr<OperatorState>(new UnionState(nullptr));
 }
 
 unique_ptr<OperatorState>
-PhysicalAdaptiveUnion::GetOperatorStateWithStaticJoinOrder(ExecutionContext &context,
-                                                           vector<idx_t> *input_join_order) const {
-	return unique_ptr<OperatorState>(new AdaptiveUnionState(input_join_order));
+PhysicalAdaptiveUnion::GetOperatorStateWithStaticJoinOrder(ExecutionContext &, vector<idx_t> *input_join_order) const {
+	return unique_ptr<OperatorState>(new UnionState(input_join_order));
 }
 
-// physical_adaptive_union.cpp:37-76
+// reference behaviour: physical_adaptive_union.cpp:37-76
 OperatorResultType PhysicalAdaptiveUnion::Execute(ExecutionContext &context, DataChunk &input, DataChunk &chunk,
-                                                  GlobalOperatorState &gstate_p, OperatorState &state_p) const {
-	auto &state = (AdaptiveUnionState &)state_p;
-	if (!context.thread.current_join_path && !state.input_join_order) {
+                                                  GlobalOperatorState &, OperatorState &state_p) const {
+	const vector<idx_t> *path = static_cast<UnionState &>(state_p).pinned_path;
+	if (!path) {
+		path = context.thread.current_join_path;
+	}
+	if (!path) {
 		throw InternalException("adaptive union without a current join path");
 	}
-	vector<idx_t> &current_join_path =
-	    state.input_join_order ? *state.input_join_order : *context.thread.current_join_path;
 	chunk.SetCardinality(input);
-	for (idx_t i = 0; i < num_columns_from_left; i++) {
-		chunk.data[i].Reference(input.data[i]);
+	// the probe side passes through
+	idx_t src = 0;
+	for (; src < num_columns_from_left; src++) {
+		chunk.data[src].Reference(input.data[src]);
 	}
-	idx_t current_offset = num_columns_from_left;
-	for (idx_t i = 0; i < current_join_path.size(); i++) {
-		idx_t join_idx = current_join_path[i];
-		idx_t target_columns_begin = join_idx == 0 ? num_columns_from_left : num_columns_per_join[join_idx - 1];
-		for (idx_t j = target_columns_begin; j < num_columns_per_join[join_idx]; j++) {
-			chunk.data[j].Reference(input.data[current_offset]);
-			current_offset++;
+	// the input carries the build columns join by join in path order: hand each group to its home span
+	for (const idx_t join : *path) {
+		const ColumnSpan &home = spans[join];
+		for (idx_t c = 0; c < home.width; c++) {
+			chunk.data[home.first + c].Reference(input.data[src++]);
 		}
 	}
 	return OperatorResultType::NEED_MORE_INPUT;

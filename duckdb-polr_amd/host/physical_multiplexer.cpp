@@ -1,9 +1,53 @@
 #include "physical_multiplexer.hpp"
 
+#include <algorithm>
 #include <iostream>
-#include <sstream>
 
 namespace duckdb_polr {
+
+namespace {
+
+// per-executor state of the operator (the reference's MultiplexerState, physical_multiplexer.cpp:20-82): the
+// routing core, the strategy object in front of it and the two logs
+struct MpxState : public OperatorState {
+	polr::MultiplexerCore core; // resistances, counters, strategy state
+	unique_ptr<RoutingStrategy> strategy;
+	vector<idx_t> per_round;               // log_tuples_routed: intermediates of every closed run
+	vector<vector<idx_t>> per_path_alt;    // ALTERNATE: one column per path
+};
+
+MpxState &Of(OperatorState &s) {
+	return static_cast<MpxState &>(s);
+}
+
+template <class S>
+RoutingStrategy *Make(polr::MultiplexerCore *core, idx_t init_tuples) {
+	return new S(core, init_tuples);
+}
+RoutingStrategy *MakeAlternate(polr::MultiplexerCore *core, idx_t) {
+	return new AlternateRoutingStrategy(core);
+}
+RoutingStrategy *MakeDefault(polr::MultiplexerCore *core, idx_t) {
+	return new DefaultPathRoutingStrategy(core, 0);
+}
+
+// strategy objects by MultiplexerRouting value (config.hpp:41-50)
+struct StrategyEntry {
+	MultiplexerRouting routing;
+	RoutingStrategy *(*make)(polr::MultiplexerCore *, idx_t);
+};
+const StrategyEntry kStrategies[] = {
+    {MultiplexerRouting::ALTERNATE, MakeAlternate},
+    {MultiplexerRouting::ADAPTIVE_REINIT, Make<AdaptiveReinitRoutingStrategy>},
+    {MultiplexerRouting::DYNAMIC, Make<DynamicRoutingStrategy>},
+    {MultiplexerRouting::INIT_ONCE, Make<InitOnceRoutingStrategy>},
+    {MultiplexerRouting::OPPORTUNISTIC, Make<OpportunisticRoutingStrategy>},
+    {MultiplexerRouting::DEFAULT_PATH, MakeDefault},
+    {MultiplexerRouting::BACKPRESSURE, MakeDefault},
+    {MultiplexerRouting::EXPONENTIAL_BACKOFF, Make<ExponentialBackoffRoutingStrategy>},
+};
+
+} // namespace
 
 PhysicalMultiplexer::PhysicalMultiplexer(vector<LogicalType> types, idx_t estimated_cardinality, idx_t path_count_p,
                                          double regret_budget_p, MultiplexerRouting routing_p)
@@ -14,155 +58,124 @@ PhysicalMultiplexer::PhysicalMultiplexer(vector<LogicalType> types, idx_t estima
 	}
 }
 
-// MultiplexerState, physical_multiplexer.cpp:20-82
-class MultiplexerState : public OperatorState {
-public:
-	MultiplexerState(idx_t path_count, MultiplexerRouting routing, double regret_budget, idx_t init_tuple_count,
-	                 idx_t multiplier) {
-		core.Init((uint32_t)routing, (uint32_t)path_count, regret_budget, init_tuple_count, multiplier);
-		switch (routing) {
-		case MultiplexerRouting::ADAPTIVE_REINIT:
-			routing_strategy.reset(new AdaptiveReinitRoutingStrategy(&core, init_tuple_count));
-			break;
-		case MultiplexerRouting::ALTERNATE:
-			routing_strategy.reset(new AlternateRoutingStrategy(&core));
-			break;
-		case MultiplexerRouting::DYNAMIC:
-			routing_strategy.reset(new DynamicRoutingStrategy(&core, init_tuple_count));
-			break;
-		case MultiplexerRouting::INIT_ONCE:
-			routing_strategy.reset(new InitOnceRoutingStrategy(&core, init_tuple_count));
-			break;
-		case MultiplexerRouting::OPPORTUNISTIC:
-			routing_strategy.reset(new OpportunisticRoutingStrategy(&core, init_tuple_count));
-			break;
-		case MultiplexerRouting::DEFAULT_PATH:
-		case MultiplexerRouting::BACKPRESSURE:
-			routing_strategy.reset(new DefaultPathRoutingStrategy(&core, 0));
-			break;
-		case MultiplexerRouting::EXPONENTIAL_BACKOFF:
-			routing_strategy.reset(new ExponentialBackoffRoutingStrategy(&core, init_tuple_count));
-			break;
-		default:
-			throw InternalException("unknown routing strategy");
-		}
-	}
-	polr::MultiplexerCore core; // path_resistances, historic_resistances, counters, strategy state
-	unique_ptr<RoutingStrategy> routing_strategy;
-	vector<vector<idx_t>> intermediates_alternate_mode;
-	vector<idx_t> intermediates_per_round;
-};
-
 unique_ptr<OperatorState> PhysicalMultiplexer::GetOperatorState(ExecutionContext &context) const {
-	if (context.client.config.time_resistance) {
+	const auto &cfg = context.client.config;
+	if (cfg.time_resistance) {
 		// wall-clock resistances are nondeterministic by construction; the device path keeps the default
 		throw NotImplementedException("time_resistance is outside the MI355X path");
 	}
-	return unique_ptr<OperatorState>(new MultiplexerState(path_count, routing, regret_budget,
-	                                                      context.client.config.init_tuple_count,
-	                                                      context.client.config.atc_multiplier));
+	unique_ptr<MpxState> st(new MpxState());
+	st->core.Init((uint32_t)routing, (uint32_t)path_count, regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
+	for (const auto &entry : kStrategies) {
+		if (entry.routing == routing) {
+			st->strategy.reset(entry.make(&st->core, cfg.init_tuple_count));
+		}
+	}
+	if (!st->strategy) {
+		throw InternalException("unknown routing strategy");
+	}
+	return unique_ptr<OperatorState>(st.release());
 }
 
-idx_t &PhysicalMultiplexer::GetNumCacheFlushingSkips(OperatorState &state_p) const {
-	return ((MultiplexerState &)state_p).core.num_cache_flushing_skips;
-}
-
-// physical_multiplexer.cpp:100-121
+// reference behaviour: physical_multiplexer.cpp:100-121
 OperatorResultType PhysicalMultiplexer::Execute(ExecutionContext &context, DataChunk &input, DataChunk &chunk,
-                                                GlobalOperatorState &gstate_p, OperatorState &state_p) const {
-	auto &state = (MultiplexerState &)state_p;
-	if (!state.core.first_mpx_run) {
-		FinalizePathRun(state, context.client.config.log_tuples_routed);
-	} else {
-		state.core.first_mpx_run = 0;
+                                                GlobalOperatorState &, OperatorState &mpx_state) const {
+	MpxState &st = Of(mpx_state);
+	polr::MultiplexerCore &core = st.core;
+	if (core.first_mpx_run) {
+		// very first call of this executor: nothing to close yet
+		core.first_mpx_run = 0;
 		if (routing == MultiplexerRouting::ALTERNATE) {
-			state.core.alternate_mode = 1;
-			state.intermediates_alternate_mode = vector<vector<idx_t>>(path_count);
-		}
-	}
-	auto result = state.routing_strategy->Route(input, chunk);
-	state.core.current_path_tuple_count = chunk.size();
-	state.core.current_path_idx = state.core.next_path_idx;
-	state.core.num_cache_flushing_skips = state.core.rs_cache_skips;
-	return result;
-}
-
-void PhysicalMultiplexer::IncreaseInputTupleCount(OperatorState &state_p, idx_t tuple_count) const {
-	((MultiplexerState &)state_p).core.IncreaseInputTupleCount(tuple_count);
-}
-
-// physical_multiplexer.cpp:132-174
-void PhysicalMultiplexer::FinalizePathRun(OperatorState &state_p, bool log_tuples_routed) const {
-	auto &state = (MultiplexerState &)state_p;
-	const idx_t path = state.core.current_path_idx;
-	const idx_t closed = state.core.FinalizePathRun();
-	if (log_tuples_routed) {
-		state.intermediates_per_round.push_back(closed);
-	}
-	if (!state.intermediates_alternate_mode.empty()) {
-		state.intermediates_alternate_mode[path].push_back(closed);
-	}
-}
-
-idx_t PhysicalMultiplexer::GetCurrentPathIndex(OperatorState &state_p) const {
-	return ((MultiplexerState &)state_p).core.current_path_idx;
-}
-
-void PhysicalMultiplexer::AddNumIntermediates(OperatorState &state_p, idx_t count) const {
-	((MultiplexerState &)state_p).core.AddNumIntermediates(count);
-}
-
-// physical_multiplexer.cpp:186-192
-void PhysicalMultiplexer::PrintStatistics(OperatorState &state_p) const {
-	auto &state = (MultiplexerState &)state_p;
-	std::cout << "Input tuple counts per path\n";
-	for (idx_t i = 0; i < path_count; i++) {
-		std::cout << i << ": " << state.core.input_tuple_count_per_path[i] << "\n";
-	}
-}
-
-// physical_multiplexer.cpp:194-219: same two CSV shapes
-void PhysicalMultiplexer::WriteLogToFile(OperatorState &state_p, std::ostream &file) const {
-	auto &state = (MultiplexerState &)state_p;
-	std::stringstream log;
-	if (!state.intermediates_alternate_mode.empty()) {
-		for (idx_t i = 0; i < state.intermediates_alternate_mode.size(); i++) {
-			log << "path_" << i << ",";
-		}
-		log << "\n";
-		for (idx_t i = 0; i < state.intermediates_alternate_mode.front().size(); i++) {
-			for (idx_t j = 0; j < state.intermediates_alternate_mode.size(); j++) {
-				log << state.intermediates_alternate_mode[j][i] << ",";
-			}
-			log << "\n";
+			core.alternate_mode = 1;
+			st.per_path_alt.assign(path_count, vector<idx_t>());
 		}
 	} else {
-		log << "intermediates\n";
-		for (idx_t i = 0; i < state.intermediates_per_round.size(); i++) {
-			log << state.intermediates_per_round[i] << "\n";
-		}
+		FinalizePathRun(mpx_state, context.client.config.log_tuples_routed);
 	}
-	file << log.str();
+	const OperatorResultType verdict = st.strategy->Route(input, chunk);
+	// what the run that starts now is accounted under
+	core.current_path_idx = core.next_path_idx;
+	core.current_path_tuple_count = chunk.size();
+	core.num_cache_flushing_skips = core.rs_cache_skips;
+	return verdict;
 }
 
-bool PhysicalMultiplexer::WasExecuted(OperatorState &state_p) const {
-	auto &state = (MultiplexerState &)state_p;
-	for (idx_t i = 0; i < path_count; i++) {
-		if (state.core.input_tuple_count_per_path[i] > 0) {
-			return true;
-		}
-	}
-	return false;
+void PhysicalMultiplexer::AddNumIntermediates(OperatorState &mpx_state, idx_t count) const {
+	Of(mpx_state).core.AddNumIntermediates(count);
 }
 
-const polr::MultiplexerCore &PhysicalMultiplexer::Core(OperatorState &state_p) const {
-	return ((MultiplexerState &)state_p).core;
+void PhysicalMultiplexer::IncreaseInputTupleCount(OperatorState &mpx_state, idx_t tuple_count) const {
+	Of(mpx_state).core.IncreaseInputTupleCount(tuple_count);
 }
-const vector<idx_t> &PhysicalMultiplexer::IntermediatesPerRound(OperatorState &state_p) const {
-	return ((MultiplexerState &)state_p).intermediates_per_round;
+
+// reference behaviour: physical_multiplexer.cpp:132-174 (the reward itself: MultiplexerCore::FinalizePathRun)
+void PhysicalMultiplexer::FinalizePathRun(OperatorState &mpx_state, bool log_tuples_routed) const {
+	MpxState &st = Of(mpx_state);
+	const idx_t closed_path = st.core.current_path_idx;
+	const idx_t intermediates = st.core.FinalizePathRun();
+	if (!st.per_path_alt.empty()) {
+		st.per_path_alt[closed_path].push_back(intermediates);
+	}
+	if (log_tuples_routed) {
+		st.per_round.push_back(intermediates);
+	}
 }
-const vector<vector<idx_t>> &PhysicalMultiplexer::IntermediatesAlternateMode(OperatorState &state_p) const {
-	return ((MultiplexerState &)state_p).intermediates_alternate_mode;
+
+idx_t PhysicalMultiplexer::GetCurrentPathIndex(OperatorState &mpx_state) const {
+	return Of(mpx_state).core.current_path_idx;
+}
+
+idx_t &PhysicalMultiplexer::GetNumCacheFlushingSkips(OperatorState &mpx_state) const {
+	return Of(mpx_state).core.num_cache_flushing_skips;
+}
+
+bool PhysicalMultiplexer::WasExecuted(OperatorState &mpx_state) const {
+	const uint64_t *routed = Of(mpx_state).core.input_tuple_count_per_path;
+	return std::any_of(routed, routed + path_count, [](uint64_t n) { return n != 0; });
+}
+
+// same text as the reference prints (physical_multiplexer.cpp:186-192)
+void PhysicalMultiplexer::PrintStatistics(OperatorState &mpx_state) const {
+	const polr::MultiplexerCore &core = Of(mpx_state).core;
+	std::cout << "Input tuple counts per path\n";
+	for (idx_t path = 0; path < path_count; path++) {
+		std::cout << path << ": " << core.input_tuple_count_per_path[path] << "\n";
+	}
+}
+
+// the two CSV shapes of the reference's log files (physical_multiplexer.cpp:194-219): in ALTERNATE mode one row
+// per source chunk with one column per path ("path_0,path_1,..."), otherwise one intermediates value per closed run
+void PhysicalMultiplexer::WriteLogToFile(OperatorState &mpx_state, std::ostream &file) const {
+	const MpxState &st = Of(mpx_state);
+	if (st.per_path_alt.empty()) {
+		file << "intermediates\n";
+		for (const idx_t v : st.per_round) {
+			file << v << "\n";
+		}
+		return;
+	}
+	const idx_t n_paths = st.per_path_alt.size();
+	for (idx_t path = 0; path < n_paths; path++) {
+		file << "path_" << path << ",";
+	}
+	file << "\n";
+	const idx_t n_chunks = st.per_path_alt.front().size();
+	for (idx_t chunk_no = 0; chunk_no < n_chunks; chunk_no++) {
+		for (idx_t path = 0; path < n_paths; path++) {
+			file << st.per_path_alt[path][chunk_no] << ",";
+		}
+		file << "\n";
+	}
+}
+
+const polr::MultiplexerCore &PhysicalMultiplexer::Core(OperatorState &mpx_state) const {
+	return Of(mpx_state).core;
+}
+const vector<idx_t> &PhysicalMultiplexer::IntermediatesPerRound(OperatorState &mpx_state) const {
+	return Of(mpx_state).per_round;
+}
+const vector<vector<idx_t>> &PhysicalMultiplexer::IntermediatesAlternateMode(OperatorState &mpx_state) const {
+	return Of(mpx_state).per_path_alt;
 }
 
 } // namespace duckdb_polr

@@ -16,27 +16,35 @@ namespace duckdb_polr {
 
 class POLARConfig {
 public:
-	// `joins`: the run of consecutive INNER hash joins in the optimizer's order; joins[0]->probe_types are
-	// the columns that reach the first join (what the multiplexer sees)
-	POLARConfig(ClientContext &context, vector<PhysicalHashJoin *> joins_p, idx_t source_estimated_cardinality,
+	// joins_p: the run of consecutive hash joins of the pipeline in the optimizer's order (joins_p[0]->probe_types
+	// = the columns that reach the first join, i.e. what the multiplexer sees); source_estimated_cardinality: the
+	// pipeline source's estimate (EXPONENTIAL_BACKOFF derives its window cap from it)
+	POLARConfig(ClientContext &context, JoinList joins_p, idx_t source_estimated_cardinality,
 	            unique_ptr<JoinEnumerationAlgo> enumerator_p);
+
+	// false: POLAR does not apply to this run of joins (non-INNER join, fewer than two joins, a probe key that is not a
+	// column reference, fewer than two orders); true: everything below is filled in
 	bool GenerateJoinOrders();
 
+	// ---- inputs ------------------------------------------------------------------------------------------------
 	ClientContext &context;
 	const unique_ptr<JoinEnumerationAlgo> enumerator;
-	vector<PhysicalHashJoin *> joins;
+	JoinList joins;
 	idx_t source_estimated_cardinality;
-	vector<vector<idx_t>> join_paths;
-	vector<vector<std::map<idx_t, idx_t>>> left_expression_bindings;
-	std::unordered_map<idx_t, vector<idx_t>> join_prerequisites;
-	// (source join, relative column) of every condition whose probe key is a build column of another join
-	std::map<idx_t, std::map<idx_t, std::pair<idx_t, idx_t>>> relative_column_binding_map;
-	idx_t multiplexer_idx = 0;
-	std::unique_ptr<PhysicalMultiplexer> multiplexer;
-	std::unique_ptr<PhysicalAdaptiveUnion> adaptive_union;
 	bool measure_polr_pipeline;
 	bool log_tuples_routed;
-	vector<idx_t> hash_join_idxs;
+
+	// ---- results -----------------------------------------------------------------------------------------------
+	vector<idx_t> hash_join_idxs;   // the multiplexed joins (positions in the pipeline's operator list)
+	DependencyMap join_prerequisites; // join -> joins whose build columns its probe keys read
+	// join -> condition -> (source join, column relative to that join's build columns), for dependent keys only
+	std::map<idx_t, std::map<idx_t, std::pair<idx_t, idx_t>>> relative_column_binding_map;
+	vector<JoinOrder> join_paths;   // the bank of orders; join_paths[0] = the original order
+	// per order, per position: condition -> absolute column of the probe key in that order's layout
+	vector<vector<std::map<idx_t, idx_t>>> left_expression_bindings;
+	std::unique_ptr<PhysicalMultiplexer> multiplexer;
+	std::unique_ptr<PhysicalAdaptiveUnion> adaptive_union;
+	idx_t multiplexer_idx = 0;      // where the multiplexer goes in the operator list
 	double enumeration_time_ms = 0;
 };
 

@@ -7,88 +7,97 @@
 
 namespace duckdb_polr {
 
-// polar_enumeration_algo.cpp:13-16 (libc rand(), like the reference: not reproducible across libcs)
-idx_t RandomCandidateSelector::SelectNextCandidate(const std::vector<idx_t> &join_idxs,
-                                                   const vector<PhysicalHashJoin *> &joins) {
-	return join_idxs[rand() % join_idxs.size()];
+// Candidate selection (reference behaviour: polar_enumeration_algo.cpp:13-77).  Ties go to the candidate that
+// comes first in `candidates`, as a strict "<" scan does.
+idx_t RandomCandidateSelector::SelectNextCandidate(const JoinOrder &candidates, const JoinList &) {
+	// libc rand(), like the reference: not reproducible across libcs
+	return candidates[rand() % candidates.size()];
 }
 
-// :18-30
-idx_t MinCardinalitySelector::SelectNextCandidate(const std::vector<idx_t> &join_idxs,
-                                                  const vector<PhysicalHashJoin *> &joins) {
-	idx_t min_card = std::numeric_limits<idx_t>::max();
-	idx_t selected_candidate = 0;
-	for (idx_t i = 0; i < join_idxs.size(); i++) {
-		auto *join = joins[join_idxs[i]];
-		if (join->estimated_cardinality < min_card) {
-			min_card = join->estimated_cardinality;
-			selected_candidate = join_idxs[i];
+idx_t MinCardinalitySelector::SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins) {
+	if (candidates.empty()) {
+		return 0;
+	}
+	return *std::min_element(candidates.begin(), candidates.end(), [&](idx_t a, idx_t b) {
+		return joins[a]->estimated_cardinality < joins[b]->estimated_cardinality;
+	});
+}
+
+idx_t UncertainCardinalitySelector::SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins) {
+	// a join's score is computed once and remembered: uncertainty level x estimated cardinality
+	auto score = [&](idx_t j) {
+		auto it = uncertainties.find(j);
+		if (it == uncertainties.end()) {
+			it = uncertainties.emplace(j, joins[j]->uncertainty_level * joins[j]->estimated_cardinality).first;
+		}
+		return it->second;
+	};
+	if (candidates.empty()) {
+		return 0;
+	}
+	idx_t best = candidates.front();
+	for (const idx_t j : candidates) {
+		if (score(j) < score(best)) {
+			best = j;
 		}
 	}
-	return selected_candidate;
+	return best;
 }
 
-// :57-77
-idx_t UncertainCardinalitySelector::SelectNextCandidate(const std::vector<idx_t> &join_idxs,
-                                                        const vector<PhysicalHashJoin *> &joins) {
-	idx_t min_card = std::numeric_limits<idx_t>::max();
-	idx_t selected_candidate = 0;
-	for (auto join_idx : join_idxs) {
-		auto *join = joins[join_idx];
-		if (uncertainties.find(join_idx) == uncertainties.end()) {
-			uncertainties[join_idx] = join->uncertainty_level * join->estimated_cardinality;
-		}
-		if (uncertainties[join_idx] < min_card) {
-			min_card = uncertainties[join_idx];
-			selected_candidate = join_idx;
-		}
-	}
-	return selected_candidate;
-}
-
-// :79-124
+// The enumerator the session asks for (reference behaviour: polar_enumeration_algo.cpp:79-124)
 unique_ptr<JoinEnumerationAlgo> JoinEnumerationAlgo::CreateEnumerationAlgo(ClientContext &context) {
-	unique_ptr<JoinEnumerationAlgo> algo;
+	enum class Walk { DEPTH, BREADTH, LAST_ONCE, FIRST_ONCE };
+	enum class Pick { NONE, RANDOM, MIN_CARD, UNCERTAIN };
+	Walk walk;
+	Pick pick = Pick::NONE;
 	switch (context.config.join_enumerator) {
-	case JoinEnumerator::DFS_RANDOM:
-		algo.reset(new DFSEnumeration(unique_ptr<CandidateSelector>(new RandomCandidateSelector())));
-		break;
-	case JoinEnumerator::DFS_MIN_CARD:
-		algo.reset(new DFSEnumeration(unique_ptr<CandidateSelector>(new MinCardinalitySelector())));
-		break;
-	case JoinEnumerator::DFS_UNCERTAIN:
-		algo.reset(new DFSEnumeration(unique_ptr<CandidateSelector>(new UncertainCardinalitySelector())));
-		break;
-	case JoinEnumerator::BFS_RANDOM:
-		algo.reset(new BFSEnumeration(unique_ptr<CandidateSelector>(new RandomCandidateSelector())));
-		break;
-	case JoinEnumerator::BFS_MIN_CARD:
-		algo.reset(new BFSEnumeration(unique_ptr<CandidateSelector>(new MinCardinalitySelector())));
-		break;
-	case JoinEnumerator::BFS_UNCERTAIN:
-		algo.reset(new BFSEnumeration(unique_ptr<CandidateSelector>(new UncertainCardinalitySelector())));
-		break;
-	case JoinEnumerator::EACH_LAST_ONCE:
-		algo.reset(new EachLastOnceEnumeration());
-		break;
-	case JoinEnumerator::EACH_FIRST_ONCE:
-		algo.reset(new EachFirstOnceEnumeration());
-		break;
+	case JoinEnumerator::DFS_RANDOM:      walk = Walk::DEPTH;   pick = Pick::RANDOM;    break;
+	case JoinEnumerator::DFS_MIN_CARD:    walk = Walk::DEPTH;   pick = Pick::MIN_CARD;  break;
+	case JoinEnumerator::DFS_UNCERTAIN:   walk = Walk::DEPTH;   pick = Pick::UNCERTAIN; break;
+	case JoinEnumerator::BFS_RANDOM:      walk = Walk::BREADTH; pick = Pick::RANDOM;    break;
+	case JoinEnumerator::BFS_MIN_CARD:    walk = Walk::BREADTH; pick = Pick::MIN_CARD;  break;
+	case JoinEnumerator::BFS_UNCERTAIN:   walk = Walk::BREADTH; pick = Pick::UNCERTAIN; break;
+	case JoinEnumerator::EACH_LAST_ONCE:  walk = Walk::LAST_ONCE;  break;
+	case JoinEnumerator::EACH_FIRST_ONCE: walk = Walk::FIRST_ONCE; break;
 	case JoinEnumerator::SAMPLE:
-		// SelSampleEnumeration (:370-556) samples selectivities with libstdc++'s mt19937(1337) stream
-		// over plan-tree statistics the host mirror does not carry; Pipeline::Ready's own fallback when
-		// an enumerator yields < 2 orders is BFS_MIN_CARD (pipeline.cpp:216-225) -- used here directly.
-		algo.reset(new BFSEnumeration(unique_ptr<CandidateSelector>(new MinCardinalitySelector())));
+		// SelSampleEnumeration (:370-556) samples selectivities with libstdc++'s mt19937(1337) stream over
+		// plan-tree statistics the host mirror does not carry; Pipeline::Ready's own fallback when an enumerator
+		// yields < 2 orders is BFS_MIN_CARD (pipeline.cpp:216-225) -- used here directly.
+		walk = Walk::BREADTH;
+		pick = Pick::MIN_CARD;
 		break;
 	default:
 		throw InternalException("unknown join enumerator");
+	}
+	unique_ptr<CandidateSelector> selector;
+	if (pick == Pick::RANDOM) {
+		selector.reset(new RandomCandidateSelector());
+	} else if (pick == Pick::MIN_CARD) {
+		selector.reset(new MinCardinalitySelector());
+	} else if (pick == Pick::UNCERTAIN) {
+		selector.reset(new UncertainCardinalitySelector());
+	}
+	unique_ptr<JoinEnumerationAlgo> algo;
+	switch (walk) {
+	case Walk::DEPTH:
+		algo.reset(new DFSEnumeration(std::move(selector)));
+		break;
+	case Walk::BREADTH:
+		algo.reset(new BFSEnumeration(std::move(selector)));
+		break;
+	case Walk::LAST_ONCE:
+		algo.reset(new EachLastOnceEnumeration());
+		break;
+	default:
+		algo.reset(new EachFirstOnceEnumeration());
+		break;
 	}
 	algo->max_join_orders = context.config.max_join_orders;
 	return algo;
 }
 
 // :126-135
-bool JoinEnumerationAlgo::CanJoin(vector<idx_t> &r, idx_t s, std::unordered_map<idx_t, vector<idx_t>> &dependencies) {
+bool JoinEnumerationAlgo::CanJoin(vector<idx_t> &r, idx_t s, DependencyMap &dependencies) {
 	auto &prereq = dependencies[s];
 	for (const auto required_relation : prereq) {
 		if (std::find(r.begin(), r.end(), required_relation) == r.end()) {
@@ -100,9 +109,9 @@ bool JoinEnumerationAlgo::CanJoin(vector<idx_t> &r, idx_t s, std::unordered_map<
 
 // :137-150: just the default join order
 void JoinEnumerationAlgo::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-                                             std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-                                             const vector<PhysicalHashJoin *> &joins,
-                                             vector<vector<idx_t>> &join_orders) {
+                                             DependencyMap &dependencies,
+                                             const JoinList &joins,
+                                             vector<JoinOrder> &join_orders) {
 	std::vector<idx_t> default_path(hash_join_idxs.size());
 	std::iota(default_path.begin(), default_path.end(), 0);
 	join_orders.reserve(max_join_orders);
@@ -110,8 +119,8 @@ void JoinEnumerationAlgo::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs
 }
 
 // :152-189
-void DFSEnumeration::GeneratePathsRecursive(const vector<PhysicalHashJoin *> &joins,
-                                            std::unordered_map<idx_t, vector<idx_t>> &join_prerequisites,
+void DFSEnumeration::GeneratePathsRecursive(const JoinList &joins,
+                                            DependencyMap &join_prerequisites,
                                             vector<vector<idx_t>> &result, vector<idx_t> join_seq,
                                             vector<idx_t> joins_left) {
 	if (result.size() >= max_join_orders) {
@@ -141,7 +150,7 @@ void DFSEnumeration::GeneratePathsRecursive(const vector<PhysicalHashJoin *> &jo
 }
 
 // the "original join order first" fix-up shared by DFS and BFS (:573-608, :717-747)
-static void MoveOriginalOrderFirst(vector<vector<idx_t>> &join_orders, idx_t k, idx_t max_join_orders) {
+static void MoveOriginalOrderFirst(vector<JoinOrder> &join_orders, idx_t k, idx_t max_join_orders) {
 	bool contains_original = false;
 	idx_t original_idx = 0;
 	for (idx_t i = 0; i < join_orders.size(); i++) {
@@ -174,8 +183,8 @@ static void MoveOriginalOrderFirst(vector<vector<idx_t>> &join_orders, idx_t k, 
 
 // :558-608
 void DFSEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-                                        std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-                                        const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders) {
+                                        DependencyMap &dependencies,
+                                        const JoinList &joins, vector<JoinOrder> &join_orders) {
 	vector<idx_t> joins_left(hash_join_idxs.size());
 	std::iota(joins_left.begin(), joins_left.end(), 0);
 	join_orders.reserve(max_join_orders + 1);
@@ -183,56 +192,50 @@ void DFSEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
 	MoveOriginalOrderFirst(join_orders, hash_join_idxs.size(), max_join_orders);
 }
 
-// :610-638
-void EachLastOnceEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-                                                 std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-                                                 const vector<PhysicalHashJoin *> &joins,
-                                                 vector<vector<idx_t>> &join_orders) {
+// Append `sequence` to `orders` if every join in it comes after the joins it depends on.
+static void AddIfValid(JoinEnumerationAlgo &algo, const JoinOrder &sequence, DependencyMap &dependencies,
+                       vector<JoinOrder> &orders) {
+	JoinOrder placed;
+	for (const idx_t join : sequence) {
+		if (!algo.CanJoin(placed, join, dependencies)) {
+			return;
+		}
+		placed.push_back(join);
+	}
+	orders.push_back(placed);
+}
+
+// original order, then every order that moves ONE join to the end (the last join stays: that is the original)
+// (reference behaviour: polar_enumeration_algo.cpp:610-638)
+void EachLastOnceEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+                                                 const JoinList &joins, vector<JoinOrder> &join_orders) {
 	JoinEnumerationAlgo::GenerateJoinOrders(hash_join_idxs, dependencies, joins, join_orders);
-	auto default_path = join_orders.front();
-	for (idx_t i = 0; i + 1 < default_path.size(); i++) {
-		vector<idx_t> generated_path;
-		for (idx_t j = 0; j < default_path.size(); j++) {
-			if (j == i) {
-				continue;
+	const JoinOrder original = join_orders.front();
+	for (idx_t moved = 0; moved + 1 < original.size(); moved++) {
+		JoinOrder sequence;
+		for (idx_t pos = 0; pos < original.size(); pos++) {
+			if (pos != moved) {
+				sequence.push_back(original[pos]);
 			}
-			if (!CanJoin(generated_path, default_path[j], dependencies)) {
-				break;
-			}
-			generated_path.push_back(default_path[j]);
 		}
-		if (generated_path.size() == default_path.size() - 1 && CanJoin(generated_path, default_path[i], dependencies)) {
-			generated_path.push_back(default_path[i]);
-			join_orders.push_back(generated_path);
-		}
+		sequence.push_back(original[moved]);
+		AddIfValid(*this, sequence, dependencies, join_orders);
 	}
 }
 
-// :640-667
-void EachFirstOnceEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-                                                  std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-                                                  const vector<PhysicalHashJoin *> &joins,
-                                                  vector<vector<idx_t>> &join_orders) {
+// original order, then every order that moves ONE join to the front (:640-667)
+void EachFirstOnceEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+                                                  const JoinList &joins, vector<JoinOrder> &join_orders) {
 	JoinEnumerationAlgo::GenerateJoinOrders(hash_join_idxs, dependencies, joins, join_orders);
-	auto default_path = join_orders.front();
-	for (idx_t i = 1; i < default_path.size(); i++) {
-		vector<idx_t> generated_path;
-		if (!CanJoin(generated_path, default_path[i], dependencies)) {
-			continue;
-		}
-		generated_path.push_back(default_path[i]);
-		for (idx_t j = 0; j < default_path.size(); j++) {
-			if (j == i) {
-				continue;
+	const JoinOrder original = join_orders.front();
+	for (idx_t moved = 1; moved < original.size(); moved++) {
+		JoinOrder sequence {original[moved]};
+		for (idx_t pos = 0; pos < original.size(); pos++) {
+			if (pos != moved) {
+				sequence.push_back(original[pos]);
 			}
-			if (!CanJoin(generated_path, default_path[j], dependencies)) {
-				break;
-			}
-			generated_path.push_back(default_path[j]);
 		}
-		if (generated_path.size() == default_path.size()) {
-			join_orders.push_back(generated_path);
-		}
+		AddIfValid(*this, sequence, dependencies, join_orders);
 	}
 }
 
@@ -255,7 +258,7 @@ struct JoinCandidateEntry {
 };
 
 vector<idx_t> BFSEnumeration::FindJoinCandidates(idx_t join_count, vector<idx_t> &predecessors,
-                                                 std::unordered_map<idx_t, vector<idx_t>> &dependencies) {
+                                                 DependencyMap &dependencies) {
 	vector<bool> found_relation(join_count, false);
 	for (auto predecessor : predecessors) {
 		found_relation[predecessor] = true;
@@ -271,8 +274,8 @@ vector<idx_t> BFSEnumeration::FindJoinCandidates(idx_t join_count, vector<idx_t>
 
 // :687-747
 void BFSEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-                                        std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-                                        const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders) {
+                                        DependencyMap &dependencies,
+                                        const JoinList &joins, vector<JoinOrder> &join_orders) {
 	std::priority_queue<JoinCandidateEntry> queue;
 	vector<idx_t> empty_predecessors;
 	vector<idx_t> first_level = FindJoinCandidates(hash_join_idxs.size(), empty_predecessors, dependencies);

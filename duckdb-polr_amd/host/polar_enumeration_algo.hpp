@@ -10,21 +10,27 @@
 
 namespace duckdb_polr {
 
+// vocabulary of this header
+using JoinOrder = vector<idx_t>;                             // a permutation (or a prefix of one) of join indices
+using JoinList = vector<PhysicalHashJoin *>;                 // the multiplexed joins, original order
+using DependencyMap = std::unordered_map<idx_t, JoinOrder>;  // join -> joins whose build columns it is keyed by
+
+// ---- how a min-card / uncertain / random enumerator picks among the joins that may come next ------------------
 class CandidateSelector {
 public:
 	virtual ~CandidateSelector() = default;
-	virtual idx_t SelectNextCandidate(const std::vector<idx_t> &join_idxs,
-	                                  const vector<PhysicalHashJoin *> &joins_p) = 0;
+	virtual idx_t SelectNextCandidate(const JoinOrder &candidates,
+	                                  const JoinList &joins_p) = 0;
 };
 
 class RandomCandidateSelector : public CandidateSelector {
 public:
-	idx_t SelectNextCandidate(const std::vector<idx_t> &join_idxs, const vector<PhysicalHashJoin *> &joins) override;
+	idx_t SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins) override;
 };
 
 class MinCardinalitySelector : public CandidateSelector {
 public:
-	idx_t SelectNextCandidate(const std::vector<idx_t> &join_idxs, const vector<PhysicalHashJoin *> &joins) override;
+	idx_t SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins) override;
 };
 
 // UncertainCardinalitySelector (polar_enumeration_algo.cpp:32-77) walks the build side's plan tree;
@@ -32,17 +38,19 @@ public:
 // (PhysicalHashJoin::uncertainty_level, 1 + #filters/joins below the build side).
 class UncertainCardinalitySelector : public CandidateSelector {
 public:
-	idx_t SelectNextCandidate(const std::vector<idx_t> &join_idxs, const vector<PhysicalHashJoin *> &joins) override;
+	idx_t SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins) override;
 	std::unordered_map<idx_t, idx_t> uncertainties;
 };
 
+// ---- the enumerators (JoinEnumerator values of join_enumerator.hpp:15-25) --------------------------------------
+// base class = "only the original order"; max_join_orders caps the bank
 class JoinEnumerationAlgo {
 public:
 	virtual ~JoinEnumerationAlgo() = default;
 	virtual void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-	                                std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-	                                const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders);
-	bool CanJoin(vector<idx_t> &r, idx_t s, std::unordered_map<idx_t, vector<idx_t>> &dependencies);
+	                                DependencyMap &dependencies,
+	                                const JoinList &joins, vector<JoinOrder> &join_orders);
+	bool CanJoin(vector<idx_t> &r, idx_t s, DependencyMap &dependencies);
 	static unique_ptr<JoinEnumerationAlgo> CreateEnumerationAlgo(ClientContext &context);
 	idx_t max_join_orders = 24;
 };
@@ -51,10 +59,10 @@ class DFSEnumeration : public JoinEnumerationAlgo {
 public:
 	explicit DFSEnumeration(unique_ptr<CandidateSelector> selector_p) : selector(std::move(selector_p)) {
 	}
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-	                        const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders) override;
-	void GeneratePathsRecursive(const vector<PhysicalHashJoin *> &joins,
-	                            std::unordered_map<idx_t, vector<idx_t>> &join_prerequisites,
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
+	void GeneratePathsRecursive(const JoinList &joins,
+	                            DependencyMap &join_prerequisites,
 	                            vector<vector<idx_t>> &result, vector<idx_t> join_seq, vector<idx_t> joins_left);
 	const unique_ptr<CandidateSelector> selector;
 };
@@ -63,23 +71,23 @@ class BFSEnumeration : public JoinEnumerationAlgo {
 public:
 	explicit BFSEnumeration(unique_ptr<CandidateSelector> selector_p) : selector(std::move(selector_p)) {
 	}
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-	                        const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders) override;
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
 	vector<idx_t> FindJoinCandidates(idx_t join_count, vector<idx_t> &predecessors,
-	                                 std::unordered_map<idx_t, vector<idx_t>> &dependencies);
+	                                 DependencyMap &dependencies);
 	const unique_ptr<CandidateSelector> selector;
 };
 
 class EachLastOnceEnumeration : public JoinEnumerationAlgo {
 public:
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-	                        const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders) override;
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
 };
 
 class EachFirstOnceEnumeration : public JoinEnumerationAlgo {
 public:
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, std::unordered_map<idx_t, vector<idx_t>> &dependencies,
-	                        const vector<PhysicalHashJoin *> &joins, vector<vector<idx_t>> &join_orders) override;
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
 };
 
 } // namespace duckdb_polr

@@ -163,7 +163,7 @@ int polr_host_generate_join_orders(int enumerator, int routing, int k, int n_pro
 		client.config.multiplexer_routing = (MultiplexerRouting)routing;
 		client.config.max_join_orders = (idx_t)max_join_orders;
 		auto joins = MakeShapeJoins(k, n_probe_cols, n_build_cols, n_conds, cond_left_index, est_card, nullptr);
-		vector<PhysicalHashJoin *> raw;
+		JoinList raw;
 		for (auto &j : joins) {
 			raw.push_back(j.get());
 		}
@@ -221,7 +221,7 @@ int polr_host_run_pipeline(polr_ctx *ctx, polr_pipeline *pipe, int k, int n_path
 		// a POLARConfig whose join orders are the ones the device pipeline was created with
 		vector<int32_t> nb(k, 0), nc(k, 1), li(k * 2, 0);
 		auto joins = MakeShapeJoins(k, 1, nb.data(), nc.data(), li.data(), nullptr, ctx);
-		vector<PhysicalHashJoin *> raw;
+		JoinList raw;
 		for (auto &j : joins) {
 			raw.push_back(j.get());
 		}
