@@ -450,7 +450,7 @@ def main():
         line = {
             "metric": "probe-tuples/s", "value": round(value, 1), "unit": "tuples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u64 (hash + compare); f64 reward",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "dtype_note": "32-bit keys hashed and compared in 64-bit integer arithmetic; f64 only in the reward",
             "data": "synthetic",
             "config": {"workload": "%s (JOB-light 01 shape, IMDB cardinalities x%.3g: %d probe tuples after the "
                                    "company_type_id filter, builds title %d + movie_info_idx %d rows)" %
