@@ -135,6 +135,16 @@ __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, ui
                                                   uint32_t *unit_size_out, uint32_t resident_waves,
                                                   const OffsCache *oc);
 
+// unit = what one wave takes per visit: every wave gets work, never less than `gran` tuples, never more than 2048
+__device__ __forceinline__ void polr_size_units(uint64_t tuples, uint32_t waves, uint64_t gran, uint32_t *unit_size_out,
+                                                uint64_t *unit_prefix) {
+	uint64_t us = (tuples + waves - 1) / waves;
+	us = ((us + gran - 1) / gran) * gran;
+	us = us < gran ? gran : (us > 2048 ? 2048 : us);
+	unit_size_out[0] = (uint32_t)us;
+	unit_prefix[1] = (tuples + us - 1) / us;
+}
+
 // Absorb a counter bank: what RunPath feeds AddNumIntermediates (polar_pipeline_executor.cpp:486-487).  One
 // wave: lanes 0..31 sum the shards of counter j, lanes 32..63 those of j+1, a shuffle tree adds the shards.
 // Returns the sum of all k counters in lane 0 (0 elsewhere, and 0 when `discard`).
@@ -260,11 +270,7 @@ __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, ui
 	// chunk-offset cache): waves are there anyway, a small round is spread 64 tuples per wave -- the dependent-load chain of
 	// a step is the same for 64 and for 256 tuples, so more waves in parallel is strictly faster.
 	const uint64_t gran = (oc == nullptr && ((m->wide0_mask >> path) & 1u)) ? 256 : 64;
-	uint64_t us = (tuples + resident_waves - 1) / resident_waves;
-	us = ((us + gran - 1) / gran) * gran;
-	us = us < gran ? gran : (us > 2048 ? 2048 : us);
-	unit_size_out[0] = (uint32_t)us;
-	unit_prefix[1] = (tuples + us - 1) / us;
+	polr_size_units(tuples, resident_waves, gran, unit_size_out, unit_prefix);
 	polr_publish_progress(m);
 }
 
@@ -462,13 +468,28 @@ __device__ __forceinline__ bool polr_can_speculate(const volatile polr::Multiple
 
 // The router of one executor: ONE full wave, for the whole run.  lds: POLR_RES_ROUTER_DWORDS dwords.
 // cache_lds / cache_cap: the router workgroup's (otherwise unused) dynamic LDS, in 8-byte entries.
-// registered: the executor's registration counter; wpb: waves per worker workgroup.
+// registered: the executor's registration counter; expected_blocks: worker workgroups of this executor in the grid;
+// wpb: waves per worker workgroup.
 __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint32_t k, uint32_t *registered,
-                                                     uint32_t wpb, uint32_t lane, uint32_t *lds, uint64_t *cache_lds,
-                                                     uint32_t cache_cap, uint32_t *scratch_lds) {
+                                                     uint32_t expected_blocks, uint32_t wpb, uint32_t lane,
+                                                     uint32_t *lds, uint64_t *cache_lds, uint32_t cache_cap,
+                                                     uint32_t *scratch_lds) {
 	DevMpx *mg = x.mpx;
 	if (lane == 0) {
 		RES_STAMP(x, 0, 5)
+	}
+	const bool reset = (x.flags & POLR_RUN_RESET) != 0;
+	// Three independent round trips issued together at entry: the registration counter, the drop of counter bank 0
+	// for a reset run (results never read: fire and forget; it has long been performed when the first round goes
+	// out, several waited-for loads later), and the state load below.
+	uint32_t reg_early = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (reset) {
+		for (uint32_t j0 = 0; j0 < k; j0 += 2) {
+			const uint32_t j = j0 + (lane >> 5);
+			if (j < k) {
+				(void)atomicExch(&x.counts[(uint64_t)(lane & 31u) * k + j], 0ull);
+			}
+		}
 	}
 	{
 		// (independent loads, all in flight together: a plain copy loop waits for every load before the next)
@@ -506,7 +527,6 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 	if (cache_cap > POLR_OFFS_CACHE) {
 		cache_cap = POLR_OFFS_CACHE;
 	}
-	const bool reset = (x.flags & POLR_RUN_RESET) != 0;
 	if (reset) {
 		// a fresh MultiplexerState (what polr_mpx_reset does between passes), without a launch of its own
 		for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
@@ -579,7 +599,8 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 		uint32_t n_blocks = spec_blocks;
 		if (!have_spec) {
 			const unsigned long long t0 = wall_clock64();
-			while (true) {
+			n_blocks = n_steps == 0 ? reg_early : 0u; // (first step: the value requested at entry)
+			while (n_blocks == 0) {
 				n_blocks = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (n_blocks != 0 || wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
 					break;
@@ -594,9 +615,9 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 			}
 		}
 		// (a reset run drops whatever the counters still hold: first step only)
-		{
+		if (!(reset && n_steps == 0)) { // (a reset run starts on the bank it dropped at entry)
 			const uint64_t got = polr_router_step_absorb(m, mg, x.counts + (have_pending ? pend_slot : 0u) * bank_stride,
-			                                             k, lane, true, reset && n_steps == 0);
+			                                             k, lane, true, false);
 			if (lane == 0) {
 				m->core.AddNumIntermediates(got);
 				m->num_intermediates_total += got;
@@ -628,6 +649,25 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 				polr_router_route(m, round, prefix, us, n_blocks * wpb, &oc);
 			}
 			__builtin_amdgcn_wave_barrier();
+			if (pass == 0 && !have_spec && n_blocks < expected_blocks && ((volatile DevMpx *)m)->done == 0 &&
+			    ((volatile DevRound *)round)->count > (uint64_t)n_blocks * wpb * 64u) {
+				// The round is bigger than one step of the workgroups registered so far, and it may be the only one
+				// (DEFAULT_PATH): the workgroups of a launch start within a few microseconds of each other, so
+				// give the stragglers that long, then size the units for whoever is there (a device shared with
+				// other kernels: the registered ones do the work).
+				const unsigned long long t1 = wall_clock64();
+				uint32_t nb = n_blocks;
+				while (nb < expected_blocks && wall_clock64() - t1 < 500ull /* 5 us */) {
+					__builtin_amdgcn_s_sleep(1);
+					nb = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				nb = __shfl(nb, 0, 64);
+				n_blocks = nb > 4095u ? 4095u : nb;
+				if (lane == 0) {
+					polr_size_units(round->count, n_blocks * wpb, 64, us, prefix);
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
 			// (all lanes read what lane 0 left in LDS)
 			DevMpx *tgt = m;
 			DevRound *rd = round;

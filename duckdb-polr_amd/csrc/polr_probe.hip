@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 			// workgroup per CU)
 			const uint32_t state_dwords = (POLR_RES_ROUTER_DWORDS + 3u) & ~3u;
 			const uint32_t scratch_dwords = (POLR_RES_HOT_DWORDS + 1u) & ~1u;
-			polr_resident_router(x, k, &execs[e].registered, wpb, threadIdx.x & 63, lds,
+			polr_resident_router(x, k, &execs[e].registered, gridDim.x / n_exec - 1, wpb, threadIdx.x & 63, lds,
 			                     (uint64_t *)(lds + state_dwords), (dyn_dwords - state_dwords - scratch_dwords) / 2,
 			                     lds + (dyn_dwords - scratch_dwords));
 		}
