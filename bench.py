@@ -179,6 +179,10 @@ def main():
     ap.add_argument("--host-filter", action="store_true",
                     help="upload the host-computed selection instead of running the pushed-down filter of the source "
                          "scan on the device (polr_pipeline_scan_filter); either way it happens before the clock starts")
+    ap.add_argument("--morsels", type=int, default=0,
+                    help="M > 0: the executors share all source chunks and pull them M chunks at a time from one "
+                         "device-side cursor (morsel-driven, like the reference's worker threads; 120 = a row group) "
+                         "instead of each owning a fixed contiguous range")
     ap.add_argument("--streams", type=int, default=1,
                     help="P > 1: P passes in flight -- P sets of executors on P streams, each sized for 1/P of the "
                          "device (POLR_RUN_SHARE), passes enqueued round-robin; the exploration rounds of one pass "
@@ -344,7 +348,10 @@ def main():
             # fresh multiplexer states, the whole pass and the closing FinalizePathRun: one launch
             cur = [x[0] for x in sets[step_no[0] % P]]
             step_no[0] += 1
-            capi.run_resident(cur, ranges, reset=True, finish=True, share=P)
+            if args.morsels > 0:
+                capi.run_resident_morsels(cur, 0, n_chunks, args.morsels, reset=True, finish=True, share=P)
+            else:
+                capi.run_resident(cur, ranges, reset=True, finish=True, share=P)
             if fetch:
                 for ex in sets:  # (settles every stream; the statistics reported are the last pass's)
                     got = capi.finish_many([x[0] for x in ex])
@@ -459,6 +466,7 @@ def main():
                        "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
                        "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch,
+                       "chunks_per_executor": ("morsels of %d" % args.morsels) if args.morsels > 0 else "fixed ranges",
                        "build_tables": ["perfect" if ji["perfect"] else "hash" for ji in joins_info],
                        "passes_in_flight": ("%d streams, 1/%d of the device each" % (P, P)) if P > 1 else
                        ("back to back on one stream" if pipelined else "synchronised per pass")},

@@ -494,9 +494,10 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
 // The whole run in ONE launch: every executor gets a slice of the grid (its router workgroup +
 // probe workgroups), routing decisions never leave the device, the host only enqueues.  Asynchronous:
 // polr_mpx_finish / _finish_many synchronise.
-int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
-                          uint32_t n, polr_out *out, uint32_t flags) {
-	if (!ms || !chunk_begin || !chunk_end || n == 0 || !ms[0]) {
+static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
+                             uint32_t n, polr_out *out, uint32_t flags, uint64_t morsel_begin, uint64_t morsel_end,
+                             uint32_t morsel_chunks) {
+	if (!ms || n == 0 || !ms[0] || (morsel_chunks == 0 && (!chunk_begin || !chunk_end))) {
 		return POLR_E_INVALID;
 	}
 	polr_mpx *m0 = ms[0];
@@ -523,10 +524,11 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 		if (!ms[i]->chunk_offsets_owned && (!p->scan_valid || ms[i]->scan_generation != p->scan_generation)) {
 			POLR_FAIL(ctx, POLR_E_INVALID, "the pipeline was scanned again: call polr_mpx_use_scan_chunks");
 		}
-		if (chunk_begin[i] > chunk_end[i] || chunk_end[i] > ms[i]->n_chunks) {
-			POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks",
-			          (unsigned long long)chunk_begin[i], (unsigned long long)chunk_end[i],
-			          (unsigned long long)ms[i]->n_chunks);
+		const uint64_t cb = morsel_chunks ? morsel_begin : chunk_begin[i];
+		const uint64_t ce = morsel_chunks ? morsel_end : chunk_end[i];
+		if (cb > ce || ce > ms[i]->n_chunks) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks", (unsigned long long)cb,
+			          (unsigned long long)ce, (unsigned long long)ms[i]->n_chunks);
 		}
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -564,18 +566,24 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 			hipFree(m0->execs_dev);
 			m0->execs_dev = nullptr;
 		}
-		HIPCHK(ctx, hipMalloc((void **)&m0->execs_dev, (size_t)std::max<uint32_t>(n, 8) * sizeof(ResidentExec)));
+		// (+ one cache line behind the array: the morsel cursor of the run)
+		HIPCHK(ctx, hipMalloc((void **)&m0->execs_dev, (size_t)std::max<uint32_t>(n, 8) * sizeof(ResidentExec) + 64));
 		m0->execs_cap = std::max<uint32_t>(n, 8);
 	}
 	std::vector<ResidentExec> ex(n);
+	unsigned long long *cursor_dev = (unsigned long long *)((char *)m0->execs_dev + (size_t)m0->execs_cap * sizeof(ResidentExec));
 	for (uint32_t i = 0; i < n; i++) {
 		polr_mpx *m = ms[i];
 		m->res_epoch = (m->res_epoch + 1) & 0xFFFu;
 		ex[i].mpx = m->dev;
 		ex[i].sync = m->sync_dev;
 		ex[i].counts = m->counts_dev;
-		ex[i].chunk_begin = chunk_begin[i];
-		ex[i].chunk_end = chunk_end[i];
+		ex[i].chunk_begin = morsel_chunks ? 0 : chunk_begin[i];
+		ex[i].chunk_end = morsel_chunks ? 0 : chunk_end[i];
+		ex[i].morsel_cursor = morsel_chunks ? cursor_dev : nullptr;
+		ex[i].morsel_end = morsel_end;
+		ex[i].morsel_chunks = morsel_chunks;
+		ex[i].pad2 = 0;
 		ex[i].chunk_offsets = m->chunk_offsets_dev;
 		ex[i].n_chunks = m->n_chunks;
 		ex[i].n_tuples = p->n_tuples;
@@ -597,6 +605,10 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 	}
 	// (pageable source: staged by the runtime before the call returns)
 	HIPCHK(ctx, hipMemcpyAsync(m0->execs_dev, ex.data(), (size_t)n * sizeof(ResidentExec), hipMemcpyHostToDevice, st));
+	if (morsel_chunks) {
+		const unsigned long long first = morsel_begin;
+		HIPCHK(ctx, hipMemcpyAsync(cursor_dev, &first, 8, hipMemcpyHostToDevice, st));
+	}
 	DevOut dout;
 	memset(&dout, 0, sizeof(dout));
 	if (out) {
@@ -627,6 +639,19 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
 		ms[i]->pending_sync = true;
 	}
 	return POLR_OK;
+}
+
+int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
+                          uint32_t n, polr_out *out, uint32_t flags) {
+	return run_resident_impl(ms, stream, chunk_begin, chunk_end, n, out, flags, 0, 0, 0);
+}
+
+int polr_mpx_run_resident_morsels(polr_mpx **ms, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
+                                  uint32_t morsel_chunks, uint32_t n, polr_out *out, uint32_t flags) {
+	if (morsel_chunks == 0) {
+		return POLR_E_INVALID;
+	}
+	return run_resident_impl(ms, stream, nullptr, nullptr, n, out, flags, chunk_begin, chunk_end, morsel_chunks);
 }
 
 int polr_mpx_reset(polr_mpx *m, void *stream) {

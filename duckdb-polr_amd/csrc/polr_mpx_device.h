@@ -325,6 +325,12 @@ struct ResidentExec {
 	uint32_t registered; // worker workgroups of this executor that have started (zero when the run is enqueued)
 	uint32_t pad;
 	polr_mpx_stats *stats_out; // POLR_RUN_FINISH: where the closing statistics go (pinned host memory)
+	// morsel mode (morsel_cursor != nullptr): the executors of the run share the chunk range up to morsel_end and
+	// pull it `morsel_chunks` chunks at a time from the cursor, as the reference's worker threads pull morsels from
+	// the parallel scan state; chunk_begin / chunk_end are ignored
+	unsigned long long *morsel_cursor;
+	uint64_t morsel_end;
+	uint32_t morsel_chunks, pad2;
 	unsigned long long *stamps; // diagnostic builds only (POLR_DIAG_STAMPS), else nullptr
 };
 
@@ -543,8 +549,8 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 	}
 	if (lane == 0) {
 		// what polr_mpx_set_range_kernel does for a per-round run
-		m->chunk_idx = x.chunk_begin;
-		m->chunk_end = x.chunk_end;
+		m->chunk_idx = x.morsel_cursor ? 0 : x.chunk_begin;
+		m->chunk_end = x.morsel_cursor ? 0 : x.chunk_end;
 		m->chunk_offsets = x.chunk_offsets;
 		m->n_chunks = x.n_chunks;
 		m->n_tuples = x.n_tuples;
@@ -621,6 +627,15 @@ __device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint
 			if (lane == 0) {
 				m->core.AddNumIntermediates(got);
 				m->num_intermediates_total += got;
+			}
+		}
+		if (lane == 0 && x.morsel_cursor && m->chunk_idx >= m->chunk_end) {
+			// this executor's morsel is used up (or it has none yet): pull the next one
+			const unsigned long long next = atomicAdd(x.morsel_cursor, (unsigned long long)x.morsel_chunks);
+			if (next < x.morsel_end) {
+				m->chunk_idx = next;
+				m->chunk_end = next + x.morsel_chunks < x.morsel_end ? next + x.morsel_chunks : x.morsel_end;
+				m->done = 0;
 			}
 		}
 		n_steps++;

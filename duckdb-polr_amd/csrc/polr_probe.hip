@@ -956,6 +956,10 @@ __global__ __launch_bounds__(256, 4) void polr_resident_kernel(const DevPipeline
 		x.flags = uni(xp->flags);
 		x.stats_out = (polr_mpx_stats *)uni64((uint64_t)xp->stats_out);
 		x.stamps = (unsigned long long *)uni64((uint64_t)xp->stamps);
+		x.morsel_cursor = (unsigned long long *)uni64((uint64_t)xp->morsel_cursor);
+		x.morsel_end = uni64(xp->morsel_end);
+		x.morsel_chunks = uni(xp->morsel_chunks);
+		x.pad2 = 0;
 	}
 	if (b == 0) {
 		if (wave_in_block == 0) {

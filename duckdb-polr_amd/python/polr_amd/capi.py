@@ -29,7 +29,7 @@ EXPORTS = [
     "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
-    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident",
+    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_morsels",
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
 ]
 
@@ -162,6 +162,7 @@ def load():
     L.polr_out_aggregate.argtypes = [vp, vp, vp, u32, vp]
     L.polr_out_aggregate_grouped.argtypes = [vp, vp, vp, u32, vp, u32, vp, C.c_uint64, vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
+    L.polr_mpx_run_resident_morsels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
     _lib = L
@@ -589,6 +590,17 @@ def run_resident(mpxs, ranges, out=None, reset=False, finish=False, share=1):
     e = np.ascontiguousarray([r[1] for r in ranges], dtype=np.uint64)
     ctx.check(ctx.L.polr_mpx_run_resident(hs, None, b.ctypes.data, e.ctypes.data, n, out.h if out else None,
                                           (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) | ((share & 0xFF) << 8 if share > 1 else 0)))
+
+
+def run_resident_morsels(mpxs, chunk_begin, chunk_end, morsel_chunks=120, out=None, reset=False, finish=False, share=1):
+    """polr_mpx_run_resident_morsels: the executors share [chunk_begin, chunk_end) and pull morsels from one cursor"""
+    ctx = mpxs[0].ctx
+    n = len(mpxs)
+    hs = (C.c_void_p * n)(*[m.h for m in mpxs])
+    ctx.check(ctx.L.polr_mpx_run_resident_morsels(hs, None, chunk_begin, chunk_end, morsel_chunks, n,
+                                                  out.h if out else None,
+                                                  (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) |
+                                                  ((share & 0xFF) << 8 if share > 1 else 0)))
 
 
 def finish_many(mpxs):

@@ -348,6 +348,14 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
 #define POLR_RUN_SHARE(d) (((uint32_t)(d) & 0xFFu) << 8)
 int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                           uint32_t n, polr_out *out, uint32_t flags);
+/* Morsel-driven variant: the n executors SHARE the chunks [chunk_begin, chunk_end) and pull them `morsel_chunks`
+ * chunks at a time from one device-side cursor -- the reference's worker threads pulling morsels from the
+ * parallel scan state (a row group = 120 vectors; pipeline.cpp:145-174, table_scan.cpp) -- so a skewed source
+ * cannot leave one executor with the expensive end of the table.  Which executor sees which morsel depends on
+ * timing (as in the multi-threaded reference): result row set and COUNT(*) are deterministic, per-executor traces
+ * and total intermediates are not. */
+int polr_mpx_run_resident_morsels(polr_mpx **ms, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
+                                  uint32_t morsel_chunks, uint32_t n, polr_out *out, uint32_t flags);
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
 /* fresh MultiplexerState (a new PipelineExecutor / a new pass over the source) */
 int polr_mpx_reset(polr_mpx *m, void *stream);

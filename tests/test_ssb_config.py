@@ -136,3 +136,37 @@ def test_many_rounds_published_ahead(gpu_ctx, routing):
     assert st["num_intermediates"] == ref["num_intermediates"]
     mpx.close()
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("routing", ["adaptive_reinit", "default_path", "opportunistic"])
+def test_morsel_driven_executors(gpu_ctx, routing):
+    """executors pulling 120-chunk morsels from one cursor (the reference's morsel-driven worker threads): every
+    chunk is routed exactly once -- COUNT(*), routed tuples and the output row set equal the single-executor run"""
+    from polr_amd import capi
+    wl, paths = workload()
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    k = len(wl["joins"])
+    ref_out = capi.Output(pipe, 1024, 16384)
+    one = capi.DeviceMultiplexer(pipe, routing, regret_budget=budget(routing, n))
+    capi.run_resident([one], [(0, n_chunks)], out=ref_out, reset=True, finish=True)
+    one.finish()
+    want = ref_out.fetch_ids()
+    want = want[np.lexsort(want.T[::-1])]
+    for n_exec, morsel in ((4, 120), (7, 33), (3, 5000)):
+        mpxs = [capi.DeviceMultiplexer(pipe, routing, regret_budget=budget(routing, n)) for _ in range(n_exec)]
+        out = capi.Output(pipe, 1024, 16384)
+        capi.run_resident_morsels(mpxs, 0, n_chunks, morsel, out=out, reset=True, finish=True)
+        stats = capi.finish_many(mpxs)
+        assert sum(sum(st["input_tuple_count_per_path"]) for st in stats) == n
+        assert sum(sum(st["stage_out"][p][k - 1] for p in range(3)) for st in stats) == GOLD["count_star"]
+        got = out.fetch_ids()
+        assert np.array_equal(got[np.lexsort(got.T[::-1])], want)
+        for m in mpxs:
+            m.close()
+    one.close()
+    pipe.close()
