@@ -138,7 +138,11 @@ __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, ui
 // unit = what one wave takes per visit: every wave gets work, never less than `gran` tuples, never more than 2048
 __device__ __forceinline__ void polr_size_units(uint64_t tuples, uint32_t waves, uint64_t gran, uint32_t *unit_size_out,
                                                 uint64_t *unit_prefix) {
-	uint64_t us = (tuples + waves - 1) / waves;
+	// whole passes over the waves: a round of 1.18 x (waves x 2048) tuples is cut into 2 x waves units of ~1200, not
+	// into 1.18 x waves units of 2048 (where a fifth of the waves would do double duty while the rest wait)
+	const uint64_t per_pass = (uint64_t)waves * 2048u;
+	const uint64_t passes = tuples ? (tuples + per_pass - 1) / per_pass : 1;
+	uint64_t us = (tuples + waves * passes - 1) / (waves * passes);
 	us = ((us + gran - 1) / gran) * gran;
 	us = us < gran ? gran : (us > 2048 ? 2048 : us);
 	unit_size_out[0] = (uint32_t)us;
