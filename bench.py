@@ -162,12 +162,13 @@ def main():
     ap.add_argument("--init-tuple-count", type=int, default=1024)
     ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
     ap.add_argument("--max-join-orders", type=int, default=8, help="SET max_join_orders (bank size cap)")
-    ap.add_argument("--executors", type=int, default=8,
+    ap.add_argument("--executors", type=int, default=0,
                     help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
                          "contiguous share of the source chunks -- the counterpart of the reference's worker "
                          "threads (one PipelineExecutor + MultiplexerState per thread, pipeline.cpp:145-174). "
-                         "Default 8 = one executor per XCD of the MI355X; 1 = the single-executor trace the parity "
-                         "tests pin against the single-threaded reference")
+                         "0 (default) = 8, one executor per XCD of the MI355X, and 64 for partitions of more than 65 536 "
+                         "chunks (table-sized adaptive runs hide their exploration rounds behind each other); 1 = "
+                         "the single-executor trace the parity tests pin against the single-threaded reference")
     ap.add_argument("--launch", default="resident", choices=["resident", "rounds"],
                     help="resident: the whole pass is ONE launch (device-resident routing loop, "
                          "polr_mpx_run_resident); rounds: one self-routing launch per routing round "
@@ -320,7 +321,8 @@ def main():
     if not device_scan:
         offs = chunk_offsets_for(sel, n_rows, V)
         n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
-    E = max(1, min(args.executors, n_chunks))
+    want_e = args.executors if args.executors > 0 else (64 if n_chunks > 65536 else 8)
+    E = max(1, min(want_e, n_chunks))
     P = max(1, args.streams) if args.launch == "resident" and not args.sync_every_step else 1
     sets = []
     for _p in range(P):
