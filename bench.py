@@ -476,7 +476,7 @@ def main():
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],
             "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
-            "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch": pipe.launch_info(False),
+            "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch_info": pipe.launch_info(False),
         }
         # COUNT(*) of the pass = output tuples of the last join over all join orders; next to the reference's answer
         line["count_star"] = int(sum(st["stage_out"][p][k - 1] for p in range(len(paths))))
