@@ -125,6 +125,7 @@ extern "C" {
 
 int polr_out_aggregate(polr_out *o, void *stream, const polr_agg_spec *specs, uint32_t n_aggs,
                        polr_agg_value *results) {
+	POLR_ENTRY();
 	if (!o || !specs || !results || n_aggs == 0) {
 		return POLR_E_INVALID;
 	}

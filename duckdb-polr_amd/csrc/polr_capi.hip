@@ -6,7 +6,25 @@
 
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "polr_internal.h"
+
+void polr_trace_stale(const char *where) {
+	static const int enabled = [] {
+		const char *v = getenv("POLR_DEBUG_HIP_ERRORS");
+		return (v && v[0] && v[0] != '0') ? 1 : 0;
+	}();
+	static thread_local const char *previous = "(none)";
+	if (enabled) {
+		const hipError_t e = hipGetLastError(); // (reads and clears)
+		if (e != hipSuccess) {
+			fprintf(stderr, "[polr] HIP error '%s' was pending on entry of %s; previous entry point: %s\n",
+			        hipGetErrorString(e), where, previous);
+		}
+		previous = where;
+	}
+}
 
 extern "C" {
 
@@ -15,6 +33,7 @@ int polr_abi_version(void) {
 }
 
 int polr_ctx_create(int device_id, polr_ctx **out) {
+	POLR_ENTRY();
 	if (!out) {
 		return POLR_E_INVALID;
 	}
@@ -46,13 +65,21 @@ int polr_ctx_create(int device_id, polr_ctx **out) {
 }
 
 void polr_ctx_destroy(polr_ctx *ctx) {
+	POLR_ENTRY();
 	if (!ctx) {
 		return;
+	}
+	if (ctx->closed) {
+		return; // (destroyed twice: the object only lives on for its children)
 	}
 	hipSetDevice(ctx->device);
 	hipStreamSynchronize(ctx->stream);
 	hipStreamDestroy(ctx->stream);
-	delete ctx;
+	// objects created on this context may outlive it (they hold references): what they still do -- free their
+	// device memory -- needs the device ordinal only; the default stream stands in for the destroyed one
+	ctx->stream = nullptr;
+	ctx->closed = true;
+	polr_ctx_release(ctx);
 }
 
 const char *polr_last_error(const polr_ctx *ctx) {
@@ -60,6 +87,7 @@ const char *polr_last_error(const polr_ctx *ctx) {
 }
 
 int polr_ctx_sync(polr_ctx *ctx, void *stream) {
+	POLR_ENTRY();
 	if (!ctx) {
 		return POLR_E_INVALID;
 	}
@@ -184,6 +212,7 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------------
 int polr_ht_upload_columns(polr_ctx *ctx, const polr_col *keys, uint32_t n_keys, const polr_col *payload,
                            uint32_t n_payload, uint64_t n_rows, polr_ht **out) {
+	POLR_ENTRY();
 	if (!ctx || !out || !keys) {
 		return POLR_E_INVALID;
 	}
@@ -194,7 +223,7 @@ int polr_ht_upload_columns(polr_ctx *ctx, const polr_col *keys, uint32_t n_keys,
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_ht *ht = new polr_ht();
-	ht->ctx = ctx;
+	ht->ctx = polr_ctx_retain(ctx);
 	ht->n_keys = n_keys;
 	ht->n_payload = n_payload;
 	ht->n_rows_in = n_rows;
@@ -225,6 +254,7 @@ int polr_ht_upload_columns(polr_ctx *ctx, const polr_col *keys, uint32_t n_keys,
 int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32_t row_width,
                         const uint32_t *col_offset, const uint32_t *col_width, const uint32_t *col_flags,
                         uint32_t n_keys, uint32_t n_payload, polr_ht **out) {
+	POLR_ENTRY();
 	if (!ctx || !out || (!rows && n_rows) || !col_offset || !col_width) {
 		return POLR_E_INVALID;
 	}
@@ -245,7 +275,7 @@ int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_ht *ht = new polr_ht();
-	ht->ctx = ctx;
+	ht->ctx = polr_ctx_retain(ctx);
 	ht->n_keys = n_keys;
 	ht->n_payload = n_payload;
 	ht->n_rows_in = n_rows;
@@ -300,6 +330,7 @@ int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32
 }
 
 int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
+	POLR_ENTRY();
 	if (!ht) {
 		return POLR_E_INVALID;
 	}
@@ -442,6 +473,7 @@ static int alloc_perfect_cols(polr_ht *ht, uint64_t size) {
 }
 
 int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream) {
+	POLR_ENTRY();
 	if (!ht) {
 		return POLR_E_INVALID;
 	}
@@ -547,6 +579,7 @@ int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, 
 }
 
 int polr_ht_finalize_auto(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream, uint32_t *kind_out) {
+	POLR_ENTRY();
 	if (!ht) {
 		return POLR_E_INVALID;
 	}
@@ -573,6 +606,7 @@ int polr_ht_finalize_auto(polr_ht *ht, int64_t min_value, int64_t max_value, voi
 
 int polr_pht_upload(polr_ctx *ctx, uint32_t key_width, uint32_t key_flags, int64_t min_value, int64_t max_value,
                     const uint8_t *bitmap, const polr_col *payload, uint32_t n_payload, polr_ht **out) {
+	POLR_ENTRY();
 	if (!ctx || !out || !bitmap) {
 		return POLR_E_INVALID;
 	}
@@ -585,7 +619,7 @@ int polr_pht_upload(polr_ctx *ctx, uint32_t key_width, uint32_t key_flags, int64
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	const uint64_t size = range + 1;
 	polr_ht *ht = new polr_ht();
-	ht->ctx = ctx;
+	ht->ctx = polr_ctx_retain(ctx);
 	ht->n_keys = 1;
 	ht->n_payload = n_payload;
 	ht->key_signed = is_signed ? POLR_COL_SIGNED : 0;
@@ -647,6 +681,7 @@ int polr_pht_upload(polr_ctx *ctx, uint32_t key_width, uint32_t key_flags, int64
 }
 
 void polr_ht_destroy(polr_ht *ht) {
+	POLR_ENTRY();
 	if (!ht) {
 		return;
 	}
@@ -679,10 +714,13 @@ void polr_ht_destroy(polr_ht *ht) {
 	if (ht->payload_dev) {
 		hipFree(ht->payload_dev);
 	}
+	polr_ctx *ctx_ = ht->ctx;
 	delete ht;
+	polr_ctx_release(ctx_);
 }
 
 int polr_ht_get_info(const polr_ht *ht, polr_ht_info *info) {
+	POLR_ENTRY();
 	if (!ht || !info) {
 		return POLR_E_INVALID;
 	}
@@ -735,6 +773,7 @@ static void ht_buffers(const polr_ht *ht, std::vector<void *> &ptrs, std::vector
 
 int polr_ht_export(const polr_ht *ht, void *meta, uint64_t *meta_bytes, void **dev_ptrs, uint64_t *dev_bytes,
                    uint32_t *n_buffers) {
+	POLR_ENTRY();
 	if (!ht || !meta_bytes || !n_buffers) {
 		return POLR_E_INVALID;
 	}
@@ -794,6 +833,7 @@ int polr_ht_export(const polr_ht *ht, void *meta, uint64_t *meta_bytes, void **d
 }
 
 int polr_ht_alloc_like(polr_ctx *ctx, const void *meta, uint64_t meta_bytes, polr_ht **out) {
+	POLR_ENTRY();
 	if (!ctx || !meta || !out || meta_bytes < sizeof(HtMeta)) {
 		return POLR_E_INVALID;
 	}
@@ -805,7 +845,7 @@ int polr_ht_alloc_like(polr_ctx *ctx, const void *meta, uint64_t meta_bytes, pol
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_ht *ht = new polr_ht();
-	ht->ctx = ctx;
+	ht->ctx = polr_ctx_retain(ctx);
 	ht->kind = m.kind;
 	ht->n_keys = m.n_keys;
 	ht->n_payload = m.n_payload;
@@ -939,9 +979,95 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 	}
 }
 
+// Flat pipelines (polr_flat_device.h): every join keyed by ONE 4-byte probe column, at most one build row per key
+// (perfect bit table or unique-key hash table).  Decides the workgroup shape of the flat pool kernel and which bit
+// tables stay in LDS for the whole run (smallest first, while they fit beside the per-wave queues).
+static void plan_flat(polr_pipeline *p, std::vector<StageDesc> &sd_count) {
+	DevPipeline &c = p->host_count;
+	c.flat = 0;
+	c.n_lds_tables = 0;
+	c.lds_table_dwords = 0;
+	if (c.W != 1) {
+		return; // some join reads its key through a build column
+	}
+	for (uint32_t j = 0; j < c.k; j++) {
+		const polr_ht *ht = p->hts[j];
+		const DevJoin &dj = c.joins[j];
+		if (dj.n_keys != 1 || dj.key_src_join[0] >= 0 || dj.key_width[0] != 4) {
+			return;
+		}
+		if (ht->kind == KIND_PERFECT) {
+			// the flat lookup works in 32-bit modular arithmetic: [min, max] must lie inside the key type's domain
+			const int64_t lo = dj.key_signed ? -2147483648ll : 0ll;
+			const int64_t hi = dj.key_signed ? 2147483647ll : 4294967295ll;
+			if (ht->min_value < lo || ht->max_value > hi || ht->range > 0xFFFFFFFFull) {
+				return;
+			}
+		} else if (ht->kind != KIND_S8 || ht->capacity > (1ull << 32)) {
+			return;
+		}
+	}
+	const size_t per_wave = polr_pool_flat_wave_bytes(c.k);
+	uint32_t wpb = 4;
+	for (uint32_t w : {16u, 8u}) {
+		if (per_wave * w <= 96u * 1024) {
+			wpb = w;
+			break;
+		}
+	}
+	p->flat_wpb = wpb;
+	// one workgroup of 16 waves per CU leaves the rest of the 160 KB to the tables; smaller workgroups share a CU
+	const size_t budget = wpb == 16 ? std::min<size_t>(64u * 1024, 156u * 1024 - per_wave * wpb) : 16u * 1024;
+	std::vector<uint32_t> order;
+	for (uint32_t j = 0; j < c.k; j++) {
+		if (p->hts[j]->kind == KIND_PERFECT) {
+			order.push_back(j);
+		}
+	}
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return p->hts[a]->range < p->hts[b]->range; });
+	uint32_t off_of_join[POLR_KMAX];
+	for (uint32_t j = 0; j < POLR_KMAX; j++) {
+		off_of_join[j] = 0;
+	}
+	uint32_t used = 0;
+	for (uint32_t j : order) {
+		const polr_ht *ht = p->hts[j];
+		const uint32_t words = (uint32_t)((ht->range + 1 + 31) / 32);
+		// the same build side joined twice shares one LDS copy
+		bool shared = false;
+		for (uint32_t t = 0; t < c.n_lds_tables; t++) {
+			if (c.lds_table_src[t] == (const uint32_t *)ht->table) {
+				off_of_join[j] = c.lds_table_off[t] + 1;
+				shared = true;
+			}
+		}
+		if (shared) {
+			continue;
+		}
+		const uint32_t padded = (words + 3u) & ~3u;
+		if (((size_t)used + padded) * 4 > budget || c.n_lds_tables >= POLR_KMAX) {
+			break;
+		}
+		c.lds_table_src[c.n_lds_tables] = (const uint32_t *)ht->table;
+		c.lds_table_off[c.n_lds_tables] = used;
+		c.lds_table_len[c.n_lds_tables] = words;
+		c.n_lds_tables++;
+		off_of_join[j] = used + 1;
+		used += padded;
+	}
+	c.lds_table_dwords = used;
+	for (uint32_t q = 0; q < c.n_paths; q++) {
+		for (uint32_t pos = 0; pos < c.k; pos++) {
+			sd_count[(size_t)q * POLR_KMAX + pos].lds_off1 = off_of_join[c.paths[q].order[pos]];
+		}
+	}
+	c.flat = 1;
+}
+
 int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_probe_cols, uint64_t n_probe_rows,
                          const polr_join_desc *joins, uint32_t k, const int32_t *paths, uint32_t n_paths,
                          polr_pipeline **out) {
+	POLR_ENTRY();
 	if (!ctx || !out || !joins || !paths || (!probe_cols && n_probe_cols)) {
 		return POLR_E_INVALID;
 	}
@@ -1011,7 +1137,7 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_pipeline *p = new polr_pipeline();
-	p->ctx = ctx;
+	p->ctx = polr_ctx_retain(ctx);
 	p->k = k;
 	p->n_paths = n_paths;
 	p->n_probe_cols = n_probe_cols;
@@ -1070,6 +1196,7 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 		std::vector<StageDesc> sd_mat, sd_count;
 		build_stage_descs(p, p->host_mat, sd_mat);
 		build_stage_descs(p, p->host_count, sd_count);
+		plan_flat(p, sd_count);
 		hipError_t e = hipMalloc((void **)&p->stages_mat, sd_mat.size() * sizeof(StageDesc));
 		e = e == hipSuccess ? hipMalloc((void **)&p->stages_count, sd_count.size() * sizeof(StageDesc)) : e;
 		e = e == hipSuccess ? hipMemcpy(p->stages_mat, sd_mat.data(), sd_mat.size() * sizeof(StageDesc),
@@ -1098,6 +1225,7 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 }
 
 int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t n_sel, uint32_t flags) {
+	POLR_ENTRY();
 	if (!p) {
 		return POLR_E_INVALID;
 	}
@@ -1138,6 +1266,7 @@ int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t 
 
 int polr_pipeline_update_probe(polr_pipeline *p, uint32_t col, const void *data, const uint8_t *valid,
                                uint64_t n_rows) {
+	POLR_ENTRY();
 	if (!p || (!data && n_rows)) {
 		return POLR_E_INVALID;
 	}
@@ -1174,6 +1303,7 @@ int polr_pipeline_update_probe(polr_pipeline *p, uint32_t col, const void *data,
 }
 
 void polr_pipeline_destroy(polr_pipeline *p) {
+	POLR_ENTRY();
 	if (!p) {
 		return;
 	}
@@ -1225,13 +1355,16 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	if (p->shards_dev) {
 		hipFree(p->shards_dev);
 	}
+	polr_ctx *ctx_ = p->ctx;
 	delete p;
+	polr_ctx_release(ctx_);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Output chunks
 // ---------------------------------------------------------------------------------------------------
 int polr_out_create(polr_pipeline *p, uint32_t chunk_capacity, uint64_t max_chunks, polr_out **out) {
+	POLR_ENTRY();
 	if (!p || !out) {
 		return POLR_E_INVALID;
 	}
@@ -1244,7 +1377,7 @@ int polr_out_create(polr_pipeline *p, uint32_t chunk_capacity, uint64_t max_chun
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_out *o = new polr_out();
 	o->pipe = p;
-	o->ctx = p->ctx;
+	o->ctx = polr_ctx_retain(p->ctx);
 	memset(&o->dev, 0, sizeof(o->dev));
 	o->dev.chunk_capacity = chunk_capacity;
 	o->dev.max_chunks = (uint32_t)max_chunks;
@@ -1280,6 +1413,7 @@ int polr_out_create(polr_pipeline *p, uint32_t chunk_capacity, uint64_t max_chun
 }
 
 int polr_out_reset(polr_out *o, void *stream) {
+	POLR_ENTRY();
 	if (!o) {
 		return POLR_E_INVALID;
 	}
@@ -1292,6 +1426,7 @@ int polr_out_reset(polr_out *o, void *stream) {
 }
 
 int polr_out_stats(polr_out *o, void *stream, uint64_t *n_rows, uint64_t *n_chunks, uint32_t *overflowed) {
+	POLR_ENTRY();
 	if (!o) {
 		return POLR_E_INVALID;
 	}
@@ -1323,6 +1458,7 @@ int polr_out_stats(polr_out *o, void *stream, uint64_t *n_rows, uint64_t *n_chun
 }
 
 int polr_out_fetch_ids(polr_out *o, void *stream, uint32_t *dst, uint64_t dst_rows) {
+	POLR_ENTRY();
 	if (!o || (!dst && dst_rows)) {
 		return POLR_E_INVALID;
 	}
@@ -1356,6 +1492,7 @@ int polr_out_fetch_ids(polr_out *o, void *stream, uint32_t *dst, uint64_t dst_ro
 
 int polr_out_materialize(polr_out *o, void *stream, int32_t src_join, uint32_t src_col, void *dst_data,
                          uint8_t *dst_valid, uint64_t dst_rows, uint32_t dst_flags) {
+	POLR_ENTRY();
 	if (!o || (!dst_data && dst_rows)) {
 		return POLR_E_INVALID;
 	}
@@ -1434,6 +1571,7 @@ int polr_out_materialize(polr_out *o, void *stream, int32_t src_join, uint32_t s
 }
 
 void polr_out_destroy(polr_out *o) {
+	POLR_ENTRY();
 	if (!o) {
 		return;
 	}
@@ -1453,7 +1591,9 @@ void polr_out_destroy(polr_out *o) {
 	if (o->total_dev) {
 		hipFree(o->total_dev);
 	}
+	polr_ctx *ctx_ = o->ctx;
 	delete o;
+	polr_ctx_release(ctx_);
 }
 
 } // extern "C"
@@ -1513,6 +1653,7 @@ extern "C" {
 
 int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *rounds, uint32_t n_rounds,
                             polr_out *out, uint64_t *counts_dev) {
+	POLR_ENTRY();
 	if (!p || !rounds || !counts_dev || n_rounds == 0) {
 		return POLR_E_INVALID;
 	}
@@ -1606,6 +1747,7 @@ int polr_probe_rounds_async(polr_pipeline *p, void *stream, const polr_round *ro
 
 int polr_probe_rounds(polr_pipeline *p, void *stream, const polr_round *rounds, uint32_t n_rounds, polr_out *out,
                       uint64_t *counts) {
+	POLR_ENTRY();
 	if (!p || !counts) {
 		return POLR_E_INVALID;
 	}

@@ -78,7 +78,7 @@ struct StageDesc {
 	uint32_t sentinel_start;
 	uint32_t sentinel_count;
 	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1); 2: keys may repeat
-	uint32_t pad;
+	uint32_t lds_off1; // flat pipelines: 1 + dword offset of this join's bit table in the workgroup's LDS table area; 0 = HBM
 };
 #define STAGE_DESC_DWORDS (sizeof(StageDesc) / 4)
 
@@ -95,6 +95,14 @@ struct DevPipeline {
 	DevJoin joins[POLR_KMAX];
 	DevPath paths[POLR_PMAX];
 	const StageDesc *stages; // [n_paths][POLR_KMAX], resolved per (join order, position)
+	// flat pipelines (polr_flat_device.h): every join keyed by one 4-byte probe column with <= 1 build row per key
+	uint32_t flat;            // 1: the counting variant may run on the flat pipeline
+	uint32_t n_lds_tables;    // bit tables kept in LDS for the whole run
+	uint32_t lds_table_dwords; // their total size
+	uint32_t pad2;
+	const uint32_t *lds_table_src[POLR_KMAX]; // HBM source of LDS table t
+	uint32_t lds_table_off[POLR_KMAX];        // dword offset in the LDS table area
+	uint32_t lds_table_len[POLR_KMAX];        // dwords
 };
 
 // one routed slice; must match polr_round in include/polr_hip.h

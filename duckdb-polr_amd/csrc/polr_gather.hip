@@ -122,15 +122,23 @@ DECL_K(2)
 DECL_K(4)
 DECL_K(6)
 DECL_K(8)
-#define DECL_RES_K(KK)                                                                                                 \
-	int polr_resident_occupancy_k##KK(uint32_t W, uint32_t waves_per_block);                                          \
-	hipError_t polr_launch_resident_kernel_k##KK(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,             \
-	                                             hipStream_t stream, const DevPipeline *pipe,                        \
-	                                             const ResidentExec *execs, uint32_t n_exec, DevOut out);
-DECL_RES_K(2)
-DECL_RES_K(4)
-DECL_RES_K(6)
-DECL_RES_K(8)
+struct PoolRun;
+#define DECL_POOL_K(KK)                                                                                                \
+	size_t polr_pool_lds_bytes_k##KK(uint32_t W, uint32_t waves_per_block);                                           \
+	int polr_pool_occupancy_k##KK(uint32_t W, uint32_t waves_per_block);                                              \
+	hipError_t polr_launch_pool_kernel_k##KK(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,                 \
+	                                         hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs, \
+	                                         PoolRun *run, DevOut out);                                              \
+	size_t polr_pool_flat_lds_bytes_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                           \
+	size_t polr_pool_flat_wave_bytes_k##KK();                                                                         \
+	int polr_pool_flat_occupancy_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                              \
+	hipError_t polr_launch_pool_flat_kernel_k##KK(uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords, \
+	                                              hipStream_t stream, const DevPipeline *pipe,                        \
+	                                              const ResidentExec *execs, PoolRun *run);
+DECL_POOL_K(2)
+DECL_POOL_K(4)
+DECL_POOL_K(6)
+DECL_POOL_K(8)
 
 static uint32_t compiled_k(uint32_t k) {
 	return k <= 2 ? 2 : (k <= 4 ? 4 : (k <= 6 ? 6 : 8));
@@ -183,30 +191,57 @@ extern "C++" hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t
 	}
 }
 
-extern "C++" int polr_resident_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block) {
-	switch (compiled_k(k)) {
-	case 2:
-		return polr_resident_occupancy_k2(W, waves_per_block);
-	case 4:
-		return polr_resident_occupancy_k4(W, waves_per_block);
-	case 6:
-		return polr_resident_occupancy_k6(W, waves_per_block);
-	default:
-		return polr_resident_occupancy_k8(W, waves_per_block);
+#define POOL_SWITCH(k_, call2, call4, call6, call8)                                                                  \
+	switch (compiled_k(k_)) {                                                                                          \
+	case 2:                                                                                                            \
+		return call2;                                                                                                  \
+	case 4:                                                                                                            \
+		return call4;                                                                                                  \
+	case 6:                                                                                                            \
+		return call6;                                                                                                  \
+	default:                                                                                                           \
+		return call8;                                                                                                  \
 	}
+
+extern "C++" size_t polr_pool_lds_bytes(uint32_t k, uint32_t W, uint32_t wpb) {
+	POOL_SWITCH(k, polr_pool_lds_bytes_k2(W, wpb), polr_pool_lds_bytes_k4(W, wpb), polr_pool_lds_bytes_k6(W, wpb),
+	            polr_pool_lds_bytes_k8(W, wpb))
 }
 
-extern "C++" hipError_t polr_launch_resident_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
-                                                    hipStream_t stream, const DevPipeline *pipe,
-                                                    const ResidentExec *execs, uint32_t n_exec, DevOut out) {
-	switch (compiled_k(k)) {
-	case 2:
-		return polr_launch_resident_kernel_k2(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
-	case 4:
-		return polr_launch_resident_kernel_k4(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
-	case 6:
-		return polr_launch_resident_kernel_k6(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
-	default:
-		return polr_launch_resident_kernel_k8(W, n_blocks, waves_per_block, stream, pipe, execs, n_exec, out);
-	}
+extern "C++" int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t wpb) {
+	POOL_SWITCH(k, polr_pool_occupancy_k2(W, wpb), polr_pool_occupancy_k4(W, wpb), polr_pool_occupancy_k6(W, wpb),
+	            polr_pool_occupancy_k8(W, wpb))
+}
+
+extern "C++" hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t wpb, hipStream_t stream,
+                                                const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run,
+                                                DevOut out) {
+	POOL_SWITCH(k, polr_launch_pool_kernel_k2(W, n_blocks, wpb, stream, pipe, execs, run, out),
+	            polr_launch_pool_kernel_k4(W, n_blocks, wpb, stream, pipe, execs, run, out),
+	            polr_launch_pool_kernel_k6(W, n_blocks, wpb, stream, pipe, execs, run, out),
+	            polr_launch_pool_kernel_k8(W, n_blocks, wpb, stream, pipe, execs, run, out))
+}
+
+extern "C++" size_t polr_pool_flat_lds_bytes(uint32_t k, uint32_t wpb, uint32_t table_dwords) {
+	POOL_SWITCH(k, polr_pool_flat_lds_bytes_k2(wpb, table_dwords), polr_pool_flat_lds_bytes_k4(wpb, table_dwords),
+	            polr_pool_flat_lds_bytes_k6(wpb, table_dwords), polr_pool_flat_lds_bytes_k8(wpb, table_dwords))
+}
+
+extern "C++" size_t polr_pool_flat_wave_bytes(uint32_t k) {
+	POOL_SWITCH(k, polr_pool_flat_wave_bytes_k2(), polr_pool_flat_wave_bytes_k4(), polr_pool_flat_wave_bytes_k6(),
+	            polr_pool_flat_wave_bytes_k8())
+}
+
+extern "C++" int polr_pool_flat_occupancy(uint32_t k, uint32_t wpb, uint32_t table_dwords) {
+	POOL_SWITCH(k, polr_pool_flat_occupancy_k2(wpb, table_dwords), polr_pool_flat_occupancy_k4(wpb, table_dwords),
+	            polr_pool_flat_occupancy_k6(wpb, table_dwords), polr_pool_flat_occupancy_k8(wpb, table_dwords))
+}
+
+extern "C++" hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t wpb, uint32_t table_dwords,
+                                                     hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
+                                                     PoolRun *run) {
+	POOL_SWITCH(k, polr_launch_pool_flat_kernel_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run),
+	            polr_launch_pool_flat_kernel_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run),
+	            polr_launch_pool_flat_kernel_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run),
+	            polr_launch_pool_flat_kernel_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run))
 }

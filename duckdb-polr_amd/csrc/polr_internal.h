@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -12,12 +13,28 @@
 #include "polr_device.h"
 #include "polr_mpx_device.h"
 
+// Shared ownership: every object created on a context (build sides, pipelines, outputs, multiplexers) holds a
+// reference, so destroying them in any order -- also AFTER polr_ctx_destroy, which a garbage-collected binding does
+// routinely -- never reads a freed context (it used to: hipSetDevice(<freed>->device) failed with "invalid device
+// ordinal" and left that status in the thread's last-error slot for the next launch check to find).
 struct polr_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int n_cus = 256;
 	std::string err;
+	std::atomic<int> refs {1};
+	bool closed = false; // polr_ctx_destroy was called: the stream is gone, the object lives on for its children
 };
+
+static inline polr_ctx *polr_ctx_retain(polr_ctx *ctx) {
+	ctx->refs.fetch_add(1, std::memory_order_relaxed);
+	return ctx;
+}
+static inline void polr_ctx_release(polr_ctx *ctx) {
+	if (ctx && ctx->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+		delete ctx;
+	}
+}
 
 struct OwnedCol {
 	uint8_t *data = nullptr;
@@ -78,6 +95,7 @@ struct polr_pipeline {
 	StageDesc *stages_count = nullptr, *stages_mat = nullptr; // [n_paths][POLR_KMAX] each
 	int blocks_per_cu_count = 0, blocks_per_cu_mat = 0;       // measured residency of the path kernel
 	uint32_t wpb_count = 0, wpb_mat = 0;                      // waves per workgroup (4, or fewer when the LDS queues are wide)
+	uint32_t flat_wpb = 0;                                    // flat pipelines: waves per workgroup of the flat pool kernel
 	// launch scratch (grown on demand)
 	DevRound *rounds_dev = nullptr;
 	uint64_t *prefix_dev = nullptr;
@@ -116,6 +134,12 @@ struct polr_out {
 		}                                                                                                              \
 	} while (0)
 
+// Diagnostic (POLR_DEBUG_HIP_ERRORS=1 in the environment): every C-ABI entry point reports a HIP error that an
+// EARLIER call left in the thread's last-error slot, naming the entry point that ran before -- how a swallowed
+// HIP status is tracked down.  Off: one predictable branch.
+void polr_trace_stale(const char *where);
+#define POLR_ENTRY() polr_trace_stale(__func__)
+
 static inline hipStream_t polr_stream(polr_ctx *ctx, void *stream) {
 	return stream ? (hipStream_t)stream : ctx->stream;
 }
@@ -127,10 +151,18 @@ hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, ui
                                    hipStream_t stream, const DevPipeline *pipe, const DevRound *rounds,
                                    const uint64_t *unit_prefix, uint32_t n_rounds, const uint32_t *unit_sizes,
                                    DevOut out, unsigned long long *counts, SelfRoute sr);
-int polr_resident_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block);
-hipError_t polr_launch_resident_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block,
-                                       hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                       uint32_t n_exec, DevOut out);
+// the whole run in one launch (polr_pool.hip): routers + a pool of probe waves
+struct PoolRun;
+size_t polr_pool_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_per_block);
+int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block);
+hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, hipStream_t stream,
+                                   const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run, DevOut out);
+size_t polr_pool_flat_lds_bytes(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
+size_t polr_pool_flat_wave_bytes(uint32_t k);
+int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
+hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords,
+                                        hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
+                                        PoolRun *run);
 void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,

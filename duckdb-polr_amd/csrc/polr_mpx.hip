@@ -24,6 +24,7 @@
 
 #include "polr_internal.h"
 #include "polr_mpx_device.h"
+#include "polr_pool_device.h"
 
 struct polr_mpx {
 	polr_pipeline *pipe = nullptr;
@@ -53,9 +54,12 @@ struct polr_mpx {
 	uint32_t wide0_mask = 0;
 	uint64_t n_chunks = 0;
 	// resident launches
-	ResidentSync *sync_dev = nullptr;
-	ResidentExec *execs_dev = nullptr; // (owned by the first multiplexer of a resident run)
+	ResidentSync *sync_dev = nullptr;  // arrival counters of this executor
+	char *execs_dev = nullptr;         // run header + executor descriptors + morsel cursor (owned by the first multiplexer of a run)
 	uint32_t execs_cap = 0;
+	PoolSync *pool_dev = nullptr;      // unit rings of the runs this multiplexer leads
+	uint32_t pool_lo_cap = 0, pool_hi_cap = 0;
+	bool pool_dirty = false;           // a run was given up: rings and tickets are re-initialised before the next one
 	uint32_t res_epoch = 0;
 	polr_mpx_stats *stats_host = nullptr; // pinned, mapped: closing statistics of a POLR_RUN_FINISH run
 	polr_mpx_stats *stats_host_dev = nullptr;
@@ -180,6 +184,7 @@ __global__ void polr_mpx_finish_kernel(DevMpx *m, unsigned long long *counts, ui
 extern "C" {
 
 int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out) {
+	POLR_ENTRY();
 	if (!p || !cfg || !out) {
 		return POLR_E_INVALID;
 	}
@@ -197,7 +202,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	polr_mpx *m = new polr_mpx();
 	m->pipe = p;
-	m->ctx = p->ctx;
+	m->ctx = polr_ctx_retain(p->ctx);
 	m->cfg = *cfg;
 	m->n_chunks = (p->n_tuples + cfg->chunk_size - 1) / cfg->chunk_size;
 	const uint64_t max_log = cfg->log_rounds ? std::max<uint64_t>(cfg->max_log_rounds, 1) : 1;
@@ -249,6 +254,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 }
 
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks) {
+	POLR_ENTRY();
 	if (!m || (!offsets && n_chunks)) {
 		return POLR_E_INVALID;
 	}
@@ -276,6 +282,7 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 }
 
 int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_info *info) {
+	POLR_ENTRY();
 	if (!p || !info) {
 		return POLR_E_INVALID;
 	}
@@ -283,22 +290,29 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	const bool mat = materialize != 0;
 	const DevPipeline &dp = mat ? p->host_mat : p->host_count;
-	const uint32_t wpb = polr_waves_per_block(p, mat);
+	const bool flat = !mat && dp.flat != 0;
+	const uint32_t wpb = flat ? p->flat_wpb : polr_waves_per_block(p, mat);
 	if (wpb == 0) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
 	}
 	memset(info, 0, sizeof(*info));
 	info->waves_per_workgroup = wpb;
-	info->workgroups_per_cu = (uint32_t)std::max(0, std::min(polr_resident_occupancy(dp.k, dp.W, wpb), 8));
-	info->lds_bytes_per_workgroup = (uint32_t)polr_path_lds_bytes(dp.k, dp.W, wpb);
+	const int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb);
+	info->workgroups_per_cu = (uint32_t)std::max(0, std::min(occ, 8));
+	info->lds_bytes_per_workgroup = (uint32_t)(flat ? polr_pool_flat_lds_bytes(dp.k, wpb, dp.lds_table_dwords)
+	                                                : polr_pool_lds_bytes(dp.k, dp.W, wpb));
 	info->compiled_stages = dp.k <= 2 ? 2 : (dp.k <= 4 ? 4 : (dp.k <= 6 ? 6 : 8));
 	info->tuple_slots = dp.W;
 	info->n_cus = (uint32_t)ctx->n_cus;
+	info->flat = flat ? 1u : 0u;
+	info->lds_tables = flat ? dp.n_lds_tables : 0u;
+	info->lds_table_bytes = flat ? dp.lds_table_dwords * 4u : 0u;
 	return POLR_OK;
 }
 
 // the source chunks are the ones polr_pipeline_scan_filter produced (boundaries stay on the device)
 int polr_mpx_use_scan_chunks(polr_mpx *m) {
+	POLR_ENTRY();
 	if (!m) {
 		return POLR_E_INVALID;
 	}
@@ -450,6 +464,7 @@ static int run_pump(RunState &rs) {
 }
 
 int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk_end, polr_out *out) {
+	POLR_ENTRY();
 	if (!m) {
 		return POLR_E_INVALID;
 	}
@@ -467,6 +482,7 @@ int polr_mpx_run(polr_mpx *m, void *stream, uint64_t chunk_begin, uint64_t chunk
 // the device instead of queueing behind each other.
 int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                       uint32_t n, polr_out *out) {
+	POLR_ENTRY();
 	if (!ms || !chunk_begin || !chunk_end || n == 0) {
 		return POLR_E_INVALID;
 	}
@@ -491,9 +507,20 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
 	return rc;
 }
 
-// The whole run in ONE launch: every executor gets a slice of the grid (its router workgroup +
-// probe workgroups), routing decisions never leave the device, the host only enqueues.  Asynchronous:
+// The whole run in ONE launch (polr_pool.hip): one router wave per executor + a pool of probe waves that serves
+// the rounds of all executors; routing decisions never leave the device, the host only enqueues.  Asynchronous:
 // polr_mpx_finish / _finish_many synchronise.
+static uint32_t next_pow2_u32(uint64_t v) {
+	uint32_t p = 1;
+	while (p < v) {
+		p <<= 1;
+	}
+	return p;
+}
+
+#define POOL_HEADER_BYTES 128
+static_assert(sizeof(PoolRun) <= POOL_HEADER_BYTES, "run header");
+
 static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                              uint32_t n, polr_out *out, uint32_t flags, uint64_t morsel_begin, uint64_t morsel_end,
                              uint32_t morsel_chunks) {
@@ -503,11 +530,11 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	polr_mpx *m0 = ms[0];
 	polr_pipeline *p = m0->pipe;
 	polr_ctx *ctx = p->ctx;
-	if (n > 64) {
-		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "at most 64 executors per resident run");
+	if (n > 4096) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "at most 4096 executors per run");
 	}
 	if (p->n_tuples >= 0xFFFFFFF0ull) {
-		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "resident run: source partition too large");
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "source partition too large for 32-bit tuple positions");
 	}
 	if (out && out->pipe != p) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "output object belongs to another pipeline");
@@ -515,11 +542,6 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	for (uint32_t i = 0; i < n; i++) {
 		if (!ms[i] || ms[i]->pipe != p) {
 			return POLR_E_INVALID;
-		}
-		for (uint32_t j = 0; j < i; j++) {
-			if (ms[j] == ms[i]) {
-				POLR_FAIL(ctx, POLR_E_INVALID, "the same multiplexer twice in one resident run");
-			}
 		}
 		if (!ms[i]->chunk_offsets_owned && (!p->scan_valid || ms[i]->scan_generation != p->scan_generation)) {
 			POLR_FAIL(ctx, POLR_E_INVALID, "the pipeline was scanned again: call polr_mpx_use_scan_chunks");
@@ -531,47 +553,93 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 			          (unsigned long long)ce, (unsigned long long)ms[i]->n_chunks);
 		}
 	}
+	{
+		std::vector<polr_mpx *> sorted(ms, ms + n);
+		std::sort(sorted.begin(), sorted.end());
+		if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "the same multiplexer twice in one run");
+		}
+	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = stream ? (hipStream_t)stream : m0->own_stream;
 	const bool materialize = out != nullptr;
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
-	const uint32_t wpb = polr_waves_per_block(p, materialize);
+	const bool flat = !materialize && dp.flat != 0;
+	const uint32_t wpb = flat ? p->flat_wpb : polr_waves_per_block(p, materialize);
 	if (wpb == 0) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
 	}
-	int occ = polr_resident_occupancy(dp.k, dp.W, wpb);
+	int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb);
 	if (occ < 1) {
-		POLR_FAIL(ctx, POLR_E_HIP, "resident kernel does not fit on a CU");
+		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel does not fit on a CU");
 	}
 	occ = std::min(occ, 8);
-	// grid: a multiple of n, at least router + one worker workgroup per executor, never more than is co-resident
 	const uint32_t share = std::max<uint32_t>((flags >> 8) & 0xFFu, 1u);
 	if (share > 16) {
-		POLR_FAIL(ctx, POLR_E_INVALID, "device share 1/%u: at most 16 resident runs side by side", share);
+		POLR_FAIL(ctx, POLR_E_INVALID, "device share 1/%u: at most 16 runs side by side", share);
 	}
-	const uint32_t capacity = (uint32_t)ctx->n_cus * (uint32_t)occ / share;
-	uint32_t per_exec = capacity / n;
-	if (per_exec < 2) {
+	// grid: router workgroups first (one wave per executor), then the pool; never more than is co-resident
+	const uint32_t capacity = std::max<uint32_t>((uint32_t)ctx->n_cus * (uint32_t)occ / share, 2u);
+	const uint32_t n_router_blocks = (n + wpb - 1) / wpb;
+	if (n_router_blocks + 1 > capacity) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "%u executors do not fit on the device at once", n);
 	}
-	const uint32_t n_blocks = per_exec * n;
+	const uint32_t n_blocks = capacity;
+	const uint32_t n_workers = n_blocks - n_router_blocks;
 	for (uint32_t i = 0; i < n; i++) {
-		// (work still queued on `st` needs no host synchronisation: everything a resident run touches is
-		// ordered by the stream -- consecutive passes can be enqueued back to back)
+		// (work still queued on `st` needs no host synchronisation: everything a run touches is ordered by the
+		// stream -- consecutive passes can be enqueued back to back)
 		HIPCHK(ctx, adopt_stream(ms[i], st));
 	}
+	const size_t execs_bytes = POOL_HEADER_BYTES + (size_t)n * sizeof(ResidentExec) + 64;
 	if (m0->execs_cap < n) {
 		if (m0->execs_dev) {
 			HIPCHK(ctx, hipStreamSynchronize(st));
 			hipFree(m0->execs_dev);
 			m0->execs_dev = nullptr;
 		}
-		// (+ one cache line behind the array: the morsel cursor of the run)
-		HIPCHK(ctx, hipMalloc((void **)&m0->execs_dev, (size_t)std::max<uint32_t>(n, 8) * sizeof(ResidentExec) + 64));
-		m0->execs_cap = std::max<uint32_t>(n, 8);
+		const uint32_t cap = std::max<uint32_t>(n, 8);
+		HIPCHK(ctx, hipMalloc((void **)&m0->execs_dev, POOL_HEADER_BYTES + (size_t)cap * sizeof(ResidentExec) + 64));
+		m0->execs_cap = cap;
 	}
-	std::vector<ResidentExec> ex(n);
-	unsigned long long *cursor_dev = (unsigned long long *)((char *)m0->execs_dev + (size_t)m0->execs_cap * sizeof(ResidentExec));
+	// unit rings: sized for everything the executors of this run can have in flight (two slots each) plus the EXIT
+	// entries, with a factor of two to spare
+	const uint32_t pool_waves = n_workers * wpb;
+	const uint32_t lo_cap = next_pow2_u32(2ull * ((uint64_t)pool_waves + 8ull * n + pool_waves / 8 + 64) + 1024);
+	const uint32_t hi_cap = next_pow2_u32(4ull * 18 * n + 256);
+	if (!m0->pool_dev || m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap || m0->pool_dirty) {
+		if (m0->pool_dev && (m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap)) {
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			hipFree(m0->pool_dev);
+			m0->pool_dev = nullptr;
+		}
+		const uint32_t lc = std::max(lo_cap, m0->pool_lo_cap), hc = std::max(hi_cap, m0->pool_hi_cap);
+		const size_t bytes = sizeof(PoolSync) + (size_t)POLR_POOL_RINGS * ((size_t)lc + hc) * sizeof(PoolEntry);
+		if (!m0->pool_dev) {
+			HIPCHK(ctx, hipMalloc((void **)&m0->pool_dev, bytes));
+		}
+		HIPCHK(ctx, hipMemsetAsync(m0->pool_dev, 0, bytes, st));
+		m0->pool_lo_cap = lc;
+		m0->pool_hi_cap = hc;
+		m0->pool_dirty = false;
+	}
+	std::vector<char> host(execs_bytes, 0);
+	PoolRun *hr = (PoolRun *)host.data();
+	ResidentExec *ex = (ResidentExec *)(host.data() + POOL_HEADER_BYTES);
+	unsigned long long *cursor_dev =
+	    (unsigned long long *)(m0->execs_dev + POOL_HEADER_BYTES + (size_t)m0->execs_cap * sizeof(ResidentExec));
+	hr->sync = m0->pool_dev;
+	hr->n_exec = n;
+	hr->n_router_blocks = n_router_blocks;
+	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {
+		hr->worker_waves[r] = ((n_workers + POLR_POOL_RINGS - 1 - r) / POLR_POOL_RINGS) * wpb;
+	}
+	hr->pool_waves = pool_waves;
+	hr->lo_cap = m0->pool_lo_cap;
+	hr->hi_cap = m0->pool_hi_cap;
+	hr->routers_done = 0;
+	hr->abort = 0;
+	hr->host_words = nullptr;
 	for (uint32_t i = 0; i < n; i++) {
 		polr_mpx *m = ms[i];
 		m->res_epoch = (m->res_epoch + 1) & 0xFFFu;
@@ -594,17 +662,11 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ex[i].stats_out = m->stats_host_dev;
 		m->stats_in_host = (flags & POLR_RUN_FINISH) != 0;
 		ex[i].stamps = nullptr;
-#ifdef POLR_DIAG_STAMPS
-		if (!m->stamps_dev) {
-			HIPCHK(ctx, hipMalloc((void **)&m->stamps_dev, 4096 * 8 * 8));
-		}
-		HIPCHK(ctx, hipMemsetAsync(m->stamps_dev, 0, 4096 * 8 * 8, st));
-		ex[i].stamps = m->stamps_dev;
-#endif
 		((volatile uint32_t *)m->done_host)[1] = 0;
 	}
 	// (pageable source: staged by the runtime before the call returns)
-	HIPCHK(ctx, hipMemcpyAsync(m0->execs_dev, ex.data(), (size_t)n * sizeof(ResidentExec), hipMemcpyHostToDevice, st));
+	HIPCHK(ctx, hipMemcpyAsync(m0->execs_dev, host.data(), POOL_HEADER_BYTES + (size_t)n * sizeof(ResidentExec),
+	                           hipMemcpyHostToDevice, st));
 	if (morsel_chunks) {
 		const unsigned long long first = morsel_begin;
 		HIPCHK(ctx, hipMemcpyAsync(cursor_dev, &first, 8, hipMemcpyHostToDevice, st));
@@ -627,10 +689,14 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		}
 		HIPCHK(ctx, hipEventRecord(m0->ev_start[ev], st));
 	}
-	hipError_t e = polr_launch_resident_kernel(dp.W, dp.k, n_blocks, wpb, st, materialize ? p->dev_mat : p->dev_count,
-	                                           m0->execs_dev, n, dout);
+	const ResidentExec *execs_dev = (const ResidentExec *)(m0->execs_dev + POOL_HEADER_BYTES);
+	hipError_t e =
+	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
+	                                        (PoolRun *)m0->execs_dev)
+	         : polr_launch_pool_kernel(dp.W, dp.k, n_blocks, wpb, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
+	                                   (PoolRun *)m0->execs_dev, dout);
 	if (e != hipSuccess) {
-		POLR_FAIL(ctx, POLR_E_HIP, "resident kernel launch failed: %s", hipGetErrorString(e));
+		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel launch failed: %s", hipGetErrorString(e));
 	}
 	if (m0->timing) {
 		HIPCHK(ctx, hipEventRecord(m0->ev_stop[ev], st));
@@ -643,11 +709,13 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 
 int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                           uint32_t n, polr_out *out, uint32_t flags) {
+	POLR_ENTRY();
 	return run_resident_impl(ms, stream, chunk_begin, chunk_end, n, out, flags, 0, 0, 0);
 }
 
 int polr_mpx_run_resident_morsels(polr_mpx **ms, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
                                   uint32_t morsel_chunks, uint32_t n, polr_out *out, uint32_t flags) {
+	POLR_ENTRY();
 	if (morsel_chunks == 0) {
 		return POLR_E_INVALID;
 	}
@@ -655,6 +723,7 @@ int polr_mpx_run_resident_morsels(polr_mpx **ms, void *stream, uint64_t chunk_be
 }
 
 int polr_mpx_reset(polr_mpx *m, void *stream) {
+	POLR_ENTRY();
 	if (!m) {
 		return POLR_E_INVALID;
 	}
@@ -682,6 +751,7 @@ extern "C" int polr_mpx_dump_stamps(polr_mpx *m, unsigned long long *dst, uint32
 #endif
 
 int polr_mpx_enable_timing(polr_mpx *m, int enable) {
+	POLR_ENTRY();
 	if (!m) {
 		return POLR_E_INVALID;
 	}
@@ -690,6 +760,7 @@ int polr_mpx_enable_timing(polr_mpx *m, int enable) {
 }
 
 int polr_mpx_kernel_time(polr_mpx *m, double *total_ms, uint64_t *n_launches) {
+	POLR_ENTRY();
 	if (!m || !total_ms || !n_launches) {
 		return POLR_E_INVALID;
 	}
@@ -701,6 +772,7 @@ int polr_mpx_kernel_time(polr_mpx *m, double *total_ms, uint64_t *n_launches) {
 }
 
 int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
+	POLR_ENTRY();
 	if (!m || !stats) {
 		return POLR_E_INVALID;
 	}
@@ -727,7 +799,8 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	m->pending_sync = false;
 	if (((volatile uint32_t *)m->done_host)[2]) {
 		((volatile uint32_t *)m->done_host)[2] = 0;
-		POLR_FAIL(ctx, POLR_E_HIP, "resident run timed out waiting for its workers (results incomplete)");
+		m->pool_dirty = true;
+		POLR_FAIL(ctx, POLR_E_HIP, "run timed out waiting for its probe waves (results incomplete)");
 	}
 	if (m->timing) {
 		drain_events(m);
@@ -738,6 +811,7 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 // finish several executors: all closing kernels and read-backs are queued first, then each stream is
 // synchronised once (saves n-1 serial round trips)
 int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
+	POLR_ENTRY();
 	if (!ms || !stats || n == 0) {
 		return POLR_E_INVALID;
 	}
@@ -776,15 +850,20 @@ int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
 			((volatile uint32_t *)m->done_host)[2] = 0;
 			timed_out = true;
 		}
+		if (timed_out) {
+			ms[0]->pool_dirty = true; // (the multiplexer that leads the run owns its rings)
+			m->pool_dirty = true;
+		}
 	}
 	if (timed_out) {
-		POLR_FAIL(ctx, POLR_E_HIP, "resident run timed out waiting for its workers (results incomplete)");
+		POLR_FAIL(ctx, POLR_E_HIP, "run timed out waiting for its probe waves (results incomplete)");
 	}
 	return POLR_OK;
 }
 
 int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tuples, uint64_t *intermediates,
                        uint64_t max_rounds, uint64_t *n_rounds) {
+	POLR_ENTRY();
 	if (!m || !n_rounds) {
 		return POLR_E_INVALID;
 	}
@@ -812,6 +891,7 @@ int polr_mpx_fetch_log(polr_mpx *m, void *stream, uint32_t *path, uint64_t *tupl
 }
 
 void polr_mpx_destroy(polr_mpx *m) {
+	POLR_ENTRY();
 	if (!m) {
 		return;
 	}
@@ -865,13 +945,18 @@ void polr_mpx_destroy(polr_mpx *m) {
 	if (m->execs_dev) {
 		hipFree(m->execs_dev);
 	}
+	if (m->pool_dev) {
+		hipFree(m->pool_dev);
+	}
 	for (auto e : m->ev_start) {
 		hipEventDestroy(e);
 	}
 	for (auto e : m->ev_stop) {
 		hipEventDestroy(e);
 	}
+	polr_ctx *ctx_ = m->ctx;
 	delete m;
+	polr_ctx_release(ctx_);
 }
 
 } // extern "C"

@@ -1,0 +1,391 @@
+// duckdb-polr_amd/csrc/polr_pool.hip -- the whole run in ONE launch (gfx950): routers + a pool of probe waves.
+//
+// Grid: the first `n_router_blocks` workgroups host the routers (one WAVE per executor: the multiplexer of
+// src/execution/operator/polr/physical_multiplexer.cpp:100-184 with its RoutingStrategy, state in LDS for the whole
+// run); every other workgroup is part of the probe pool.  Protocol: polr_pool_device.h.  Two kernels per compiled
+// stage count K (-DPOLR_K):
+//   polr_pool_kernel<W, K>       the generic per-wave pipeline of polr_probe_device.h (any key source, repeated
+//                                keys, row-id output), 256-thread workgroups;
+//   polr_pool_flat_kernel<K>     the flat pipeline of polr_flat_device.h (counting runs over banks of single-key,
+//                                unique-match joins on probe columns), up to 1024-thread workgroups that share the
+//                                LDS-resident bit tables.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "polr_device.h"
+#include "polr_mpx_device.h"
+
+#ifndef POLR_K
+#error "compile with -DPOLR_K=<compiled stage count>"
+#endif
+
+#include "polr_probe_device.h"
+#include "polr_flat_device.h"
+#include "polr_pool_device.h"
+
+// LDS a router wave needs: state + round scratch | saved state of a rehearsal | window of >= 256 chunk boundaries
+#define POOL_ROUTER_STATE ((POLR_RES_ROUTER_DWORDS + 3u) & ~3u)
+#define POOL_ROUTER_SAVE ((POLR_RES_HOT_DWORDS + 3u) & ~3u)
+#define POOL_ROUTER_MIN_DWORDS (POOL_ROUTER_STATE + POOL_ROUTER_SAVE + 2u * 256u)
+
+__device__ __forceinline__ void pool_load_run(const PoolRun *run, PoolRun &rh) {
+	rh.sync = (PoolSync *)uni64((uint64_t)run->sync);
+	rh.n_exec = uni(run->n_exec);
+	rh.n_router_blocks = uni(run->n_router_blocks);
+#pragma unroll
+	for (int r = 0; r < POLR_POOL_RINGS; r++) {
+		rh.worker_waves[r] = uni(run->worker_waves[r]);
+	}
+	rh.pool_waves = uni(run->pool_waves);
+	rh.lo_cap = uni(run->lo_cap);
+	rh.hi_cap = uni(run->hi_cap);
+	rh.routers_done = 0;
+	rh.abort = 0;
+	rh.host_words = nullptr;
+}
+
+__device__ __forceinline__ void pool_load_exec(const ResidentExec *xp, ResidentExec &x) {
+	x.mpx = (DevMpx *)uni64((uint64_t)xp->mpx);
+	x.sync = (ResidentSync *)uni64((uint64_t)xp->sync);
+	x.counts = (unsigned long long *)uni64((uint64_t)xp->counts);
+	x.chunk_begin = uni64(xp->chunk_begin);
+	x.chunk_end = uni64(xp->chunk_end);
+	x.chunk_offsets = (const uint64_t *)uni64((uint64_t)xp->chunk_offsets);
+	x.n_chunks = uni64(xp->n_chunks);
+	x.n_tuples = uni64(xp->n_tuples);
+	x.epoch = uni(xp->epoch);
+	x.flags = uni(xp->flags);
+	x.registered = 0;
+	x.pad = 0;
+	x.stats_out = (polr_mpx_stats *)uni64((uint64_t)xp->stats_out);
+	x.stamps = nullptr;
+	x.morsel_cursor = (unsigned long long *)uni64((uint64_t)xp->morsel_cursor);
+	x.morsel_end = uni64(xp->morsel_end);
+	x.morsel_chunks = uni(xp->morsel_chunks);
+	x.pad2 = 0;
+}
+
+// the router waves of a router workgroup; router_dwords: LDS dwords per router wave
+__device__ __forceinline__ void pool_router_wave(const ResidentExec *execs, PoolRun *run, const PoolRun &rh, uint32_t k,
+                                                 uint32_t gran, uint32_t *lds, uint32_t router_dwords) {
+	const uint32_t wave_in_block = threadIdx.x >> 6;
+	const uint32_t wpb = blockDim.x >> 6;
+	const uint32_t exec = blockIdx.x * wpb + wave_in_block;
+	if (exec >= rh.n_exec) {
+		return;
+	}
+	ResidentExec x;
+	pool_load_exec(execs + exec, x);
+	uint32_t *base = lds + (size_t)wave_in_block * router_dwords;
+	const uint32_t cache_dwords = router_dwords - POOL_ROUTER_STATE - POOL_ROUTER_SAVE;
+	polr_pool_router(x, run, rh, exec, k, gran, threadIdx.x & 63, base, (uint64_t *)(base + POOL_ROUTER_STATE + POOL_ROUTER_SAVE),
+	                 cache_dwords / 2, base + POOL_ROUTER_STATE);
+}
+
+// a probe wave reports a finished unit: its stage counters (returning atomics), then the arrival
+template <int K>
+__device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const PoolUnit &u, uint32_t ring, uint32_t k,
+                                            uint32_t (&cnt)[K], uint32_t lane) {
+	const ResidentExec *xp = execs + u.exec;
+	unsigned long long *bank = (unsigned long long *)uni64((uint64_t)xp->counts) +
+	                           (size_t)u.slot * POLR_NSHARD * POLR_KMAX + (size_t)ring * POLR_KMAX;
+	ResidentSync *sync = (ResidentSync *)uni64((uint64_t)xp->sync);
+	if (lane == 0) {
+		unsigned long long seen = 0;
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			if (p < (int)k && cnt[p]) {
+				// returning form: the arrival below consumes `seen`, so it is issued after the adds have been performed
+				seen |= atomicAdd(&bank[p], (unsigned long long)cnt[p]);
+			}
+		}
+		atomicAdd(&sync->arrived[u.slot][ring].v, 1ull + (seen >> 63));
+	}
+#pragma unroll
+	for (int p = 0; p < K; p++) {
+		cnt[p] = 0;
+	}
+}
+
+template <int W, int K>
+__global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__restrict__ pipe,
+                                                           const ResidentExec *__restrict__ execs, PoolRun *run,
+                                                           DevOut out, uint32_t lds_per_wave) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wave_in_block = threadIdx.x >> 6;
+	const uint32_t k = uni(pipe->k);
+	PoolRun rh;
+	pool_load_run(run, rh);
+	if (blockIdx.x < rh.n_router_blocks) {
+		pool_router_wave(execs, run, rh, k, 256, lds, lds_per_wave);
+		return;
+	}
+	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) % POLR_POOL_RINGS;
+	WaveCtx<W, K> c;
+	c.k = k;
+	c.lane = threadIdx.x & 63;
+	uint32_t *base = lds + (size_t)wave_in_block * lds_per_wave;
+	c.desc = (StageDesc *)base;
+	c.q = base + K * STAGE_DESC_DWORDS;
+	c.pend_start = c.q + qtotal<W, K>();
+	c.pend_pref = c.pend_start + K * 64;
+	c.batch0 = c.pend_pref + K * 64;
+	c.wpend_start = c.batch0 + 64 * WIDE;
+	c.wpend_pref = c.wpend_start + wide_pend_slots<W, K>() * 64 * WIDE;
+#pragma unroll
+	for (int p = 0; p < K; p++) {
+		c.qsize[p] = c.pend_T[p] = c.pend_cur[p] = c.pend_base[p] = c.cnt[p] = 0;
+	}
+	c.sel = uniptr(pipe->sel);
+	c.in_pos = c.in_end = 0;
+	c.wide_mask = 0;
+	c.pend_wide = 0;
+	c.flush_token = 0;
+	c.out = out;
+	c.emit = false;
+	c.cur_chunk = NO_CHUNK;
+	c.fill = 0;
+	c.overflow = false;
+	const StageDesc *stages = uniptr(pipe->stages);
+	uint32_t cur_path = 0xFFFFFFFFu;
+	unsigned long long lo_ticket = ~0ull;
+	PoolUnit u;
+	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, u, c.lane)) {
+		if (u.path != cur_path) {
+			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)u.path * POLR_KMAX);
+			uint32_t *dst = (uint32_t *)c.desc;
+			for (uint32_t i = c.lane; i < K * STAGE_DESC_DWORDS; i += 64) {
+				dst[i] = src[i];
+			}
+			c.wide_mask = stage_wide_mask<W, K>(src, c.k);
+			cur_path = u.path;
+		}
+		c.emit = u.emit != 0 && !c.overflow;
+		c.in_pos = u.begin;
+		c.in_end = (uint64_t)u.begin + u.count;
+		run_until_idle(c, false);
+		run_until_idle(c, true);
+		pool_arrive<K>(execs, u, ring, c.k, c.cnt, c.lane);
+	}
+	if (c.cur_chunk != NO_CHUNK && c.lane == 0) {
+		out.chunk_count[c.cur_chunk] = c.fill;
+	}
+}
+
+template <int K>
+__global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline *__restrict__ pipe,
+                                                              const ResidentExec *__restrict__ execs, PoolRun *run,
+                                                              uint32_t lds_per_wave, uint32_t table_dwords,
+                                                              uint32_t router_dwords) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wave_in_block = threadIdx.x >> 6;
+	const uint32_t k = uni(pipe->k);
+	PoolRun rh;
+	pool_load_run(run, rh);
+	if (blockIdx.x < rh.n_router_blocks) {
+		pool_router_wave(execs, run, rh, k, FLAT_STEP0, lds, router_dwords);
+		return;
+	}
+	// the bit tables that fit stay in LDS for the whole run: one cooperative copy per workgroup
+	{
+		const uint32_t n_tab = uni(pipe->n_lds_tables);
+		for (uint32_t t = 0; t < n_tab; t++) {
+			const uint32_t *src = uniptr(pipe->lds_table_src[t]);
+			const uint32_t off = uni(pipe->lds_table_off[t]);
+			const uint32_t len = uni(pipe->lds_table_len[t]);
+			for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+				lds[off + i] = src[i];
+			}
+		}
+		__syncthreads();
+	}
+	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) % POLR_POOL_RINGS;
+	FlatCtx<K> c;
+	c.k = k;
+	c.lane = threadIdx.x & 63;
+	c.sel = uniptr(pipe->sel);
+	c.lds_tables = lds;
+	c.q = lds + table_dwords + (size_t)wave_in_block * lds_per_wave;
+#pragma unroll
+	for (int p = 0; p < K; p++) {
+		c.qsize[p] = c.cnt[p] = 0;
+		c.st[p].keys = nullptr;
+		c.st[p].valid = nullptr;
+		c.st[p].table = nullptr;
+		c.st[p].kind = c.st[p].min32 = c.st[p].range32 = c.st[p].lds_off1 = 0;
+		c.st[p].mask = 0;
+	}
+	c.in_pos = c.in_end = 0;
+	const StageDesc *stages = uniptr(pipe->stages);
+	uint32_t cur_path = 0xFFFFFFFFu;
+	unsigned long long lo_ticket = ~0ull;
+	PoolUnit u;
+	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, u, c.lane)) {
+		if (u.path != cur_path) {
+#pragma unroll
+			for (int p = 0; p < K; p++) {
+				if (p < (int)k) {
+					c.st[p] = flat_load_stage(stages + (uint64_t)u.path * POLR_KMAX + p);
+				}
+			}
+			cur_path = u.path;
+		}
+		c.in_pos = u.begin;
+		c.in_end = (uint64_t)u.begin + u.count;
+		flat_run_unit<K>(c);
+		pool_arrive<K>(execs, u, ring, c.k, c.cnt, c.lane);
+	}
+}
+
+// ---- launch ------------------------------------------------------------------------------------
+#define PASTE2(a, b) a##b
+#define PASTE(a, b) PASTE2(a, b)
+
+static size_t pool_wave_dwords(uint32_t W) { // per probe wave of the generic kernel, never less than a router needs
+	const size_t queues = POLR_K <= 1 ? 0 : (size_t)W * QCAP1 + (size_t)(POLR_K - 2) * W * QCAPN;
+	const size_t wslots = (POLR_K <= 4 && W <= 4) ? 2 : 1; // (wide_pend_slots<W, K>())
+	const size_t probe = (size_t)POLR_K * STAGE_DESC_DWORDS + queues + (size_t)POLR_K * 64 * 2 + 64 * WIDE + wslots * 64 * WIDE * 2;
+	return probe > POOL_ROUTER_MIN_DWORDS ? probe : POOL_ROUTER_MIN_DWORDS;
+}
+
+static size_t pool_flat_wave_dwords() {
+	return (size_t)flat_per_wave_dwords<POLR_K>();
+}
+
+// dynamic LDS of the flat kernel in dwords: tables + probe queues, never less than its router waves need (router
+// wave r of a router workgroup uses [r * stride, (r + 1) * stride) with stride = total / waves)
+static size_t pool_flat_lds_dwords(uint32_t waves_per_block, uint32_t table_dwords) {
+	const size_t probe = table_dwords + pool_flat_wave_dwords() * waves_per_block;
+	const size_t router = (size_t)POOL_ROUTER_MIN_DWORDS * waves_per_block;
+	return probe > router ? probe : router;
+}
+
+template <int W>
+static hipError_t pool_prepare(size_t lds) {
+	static size_t lds_set = 0;
+	if (lds > lds_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)polr_pool_kernel<W, POLR_K>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) {
+			return e;
+		}
+		lds_set = lds;
+	}
+	return hipSuccess;
+}
+
+static hipError_t pool_flat_prepare(size_t lds) {
+	static size_t lds_set = 0;
+	if (lds > lds_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)polr_pool_flat_kernel<POLR_K>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) {
+			return e;
+		}
+		lds_set = lds;
+	}
+	return hipSuccess;
+}
+
+template <int W>
+static int pool_occupancy_w(size_t lds, uint32_t threads) {
+	int blocks = 0;
+	if (pool_prepare<W>(lds) != hipSuccess ||
+	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_pool_kernel<W, POLR_K>, (int)threads,
+	                                                 lds) != hipSuccess) {
+		return 0;
+	}
+	return blocks;
+}
+
+template <int W>
+static hipError_t pool_launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const DevPipeline *pipe,
+                                const ResidentExec *execs, PoolRun *run, DevOut out, uint32_t lds_per_wave) {
+	hipError_t e = pool_prepare<W>(lds);
+	if (e != hipSuccess) {
+		return e;
+	}
+	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&out, (void *)&lds_per_wave};
+	// (hipLaunchKernel returns the status of THIS launch: nothing is read from the thread's last-error slot)
+	return hipLaunchKernel((const void *)polr_pool_kernel<W, POLR_K>, grid, block, args, lds, stream);
+}
+
+template <int N>
+struct PoolWc {
+	static constexpr int v = (N <= POLR_K + 1) ? N : 1;
+};
+#define POLR_FOR_EACH_W(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+
+extern "C++" size_t PASTE(polr_pool_lds_bytes_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
+	return pool_wave_dwords(W) * waves_per_block * sizeof(uint32_t);
+}
+
+extern "C++" int PASTE(polr_pool_occupancy_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
+	const size_t lds = pool_wave_dwords(W) * waves_per_block * sizeof(uint32_t);
+	if (W < 1 || W > POLR_K + 1) {
+		return 0;
+	}
+#define OCC_CASE(N)                                                                                                    \
+	if (W == N) {                                                                                                      \
+		return pool_occupancy_w<PoolWc<N>::v>(lds, 64 * waves_per_block);                                              \
+	}
+	POLR_FOR_EACH_W(OCC_CASE)
+#undef OCC_CASE
+	return 0;
+}
+
+extern "C++" hipError_t PASTE(polr_launch_pool_kernel_k, POLR_K)(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,
+                                                                 hipStream_t stream, const DevPipeline *pipe,
+                                                                 const ResidentExec *execs, PoolRun *run, DevOut out) {
+	const uint32_t per_wave = (uint32_t)pool_wave_dwords(W);
+	const size_t lds = (size_t)per_wave * waves_per_block * sizeof(uint32_t);
+	dim3 grid(n_blocks), block(64 * waves_per_block);
+	if (W < 1 || W > POLR_K + 1) {
+		return hipErrorInvalidValue;
+	}
+#define LAUNCH_CASE(N)                                                                                                 \
+	if (W == N) {                                                                                                      \
+		return pool_launch_w<PoolWc<N>::v>(grid, block, lds, stream, pipe, execs, run, out, per_wave);                 \
+	}
+	POLR_FOR_EACH_W(LAUNCH_CASE)
+#undef LAUNCH_CASE
+	return hipErrorInvalidValue;
+}
+
+extern "C++" size_t PASTE(polr_pool_flat_lds_bytes_k, POLR_K)(uint32_t waves_per_block, uint32_t table_dwords) {
+	return pool_flat_lds_dwords(waves_per_block, table_dwords) * sizeof(uint32_t);
+}
+
+extern "C++" size_t PASTE(polr_pool_flat_wave_bytes_k, POLR_K)() {
+	return pool_flat_wave_dwords() * sizeof(uint32_t);
+}
+
+extern "C++" int PASTE(polr_pool_flat_occupancy_k, POLR_K)(uint32_t waves_per_block, uint32_t table_dwords) {
+	const size_t lds = pool_flat_lds_dwords(waves_per_block, table_dwords) * sizeof(uint32_t);
+	int blocks = 0;
+	if (pool_flat_prepare(lds) != hipSuccess ||
+	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_pool_flat_kernel<POLR_K>,
+	                                                 (int)(64 * waves_per_block), lds) != hipSuccess) {
+		return 0;
+	}
+	return blocks;
+}
+
+extern "C++" hipError_t PASTE(polr_launch_pool_flat_kernel_k, POLR_K)(uint32_t n_blocks, uint32_t waves_per_block,
+                                                                      uint32_t table_dwords, hipStream_t stream,
+                                                                      const DevPipeline *pipe, const ResidentExec *execs,
+                                                                      PoolRun *run) {
+	const size_t dwords = pool_flat_lds_dwords(waves_per_block, table_dwords);
+	const size_t lds = dwords * sizeof(uint32_t);
+	hipError_t e = pool_flat_prepare(lds);
+	if (e != hipSuccess) {
+		return e;
+	}
+	uint32_t per_wave = (uint32_t)pool_flat_wave_dwords();
+	uint32_t router_dwords = (uint32_t)(dwords / waves_per_block);
+	dim3 grid(n_blocks), block(64 * waves_per_block);
+	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&per_wave, (void *)&table_dwords,
+	                (void *)&router_dwords};
+	return hipLaunchKernel((const void *)polr_pool_flat_kernel<POLR_K>, grid, block, args, lds, stream);
+}

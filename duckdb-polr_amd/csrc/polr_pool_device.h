@@ -1,0 +1,562 @@
+// duckdb-polr_amd/csrc/polr_pool_device.h -- "the whole run in one launch": device-side protocol between the
+// routers (one wave per executor, multiplexer state in LDS for the whole run) and a POOL of probe waves that
+// serve the rounds of ALL executors.
+//
+// Reference counterpart: one POLARPipelineExecutor per worker thread, each with its own MultiplexerState,
+// pulling source chunks and calling RunPath per routed slice (src/parallel/polar_pipeline_executor.cpp:255-538,
+// src/parallel/pipeline.cpp:145-174).  Here an *executor* is only the routing half of that object -- the
+// multiplexer state, its share of the source chunks, the reward feedback -- and owns no compute: every round it
+// routes is cut into units and queued; whichever probe wave is free takes the next unit.  The exploration rounds
+// of one executor therefore run beside the table-sized rounds of the others instead of idling a fixed slice of
+// the grid, and a skewed source range only makes its executor finish later, not its share of the device.
+//
+//   rings     POLR_POOL_RINGS (8) x {hi, lo}: FIFO of 16-byte unit entries.  Worker waves of workgroup b use ring
+//             b % 8 (the workgroups of one XCD under round-robin placement: speed only).  Routers deal the units
+//             of a round round-robin over the rings.  hi = rounds of <= POLR_POOL_HI_TUPLES tuples (exploration
+//             slices: latency-critical, taken first), lo = everything else.
+//   entry     two 8-byte granules, each carrying the lap tag of its ticket, written and read with relaxed
+//             agent-scope 8-byte atomics (self-validating, no fences):
+//               g0 = tag:16 | kind:2 | slot:1 | emit:1 | path:5 | 0:7 | begin:32
+//               g1 = tag:16 | exec:16 | count:32
+//   tickets   lo: a wave takes the next ticket with one returning atomicAdd on lo_head and waits for the entry of
+//             that ticket (tickets past lo_tail are simply not written yet); hi: never waited on -- taken with a CAS
+//             on hi_head only while hi_head < hi_tail.  heads/tails are monotonic across runs (tags never repeat
+//             within 65535 laps).
+//   arrival   a wave adds its k stage counters to the executor's bank [slot][ring][k] with returning atomics, then
+//             1 to arrived[slot][ring]; the router waits for the sum of the 8 shards to reach the units it has
+//             published in that slot, exchanges the counters with 0 and routes.
+//   exit      the router that finishes last publishes one EXIT entry per worker wave of every ring (lo).
+//   watchdog  every wait is bounded (POLR_RES_TIMEOUT_TICKS); a timeout raises `abort` in the run header, which every
+//             waiter polls: a lost wave is an error (POLR_E_HIP from polr_mpx_finish), never a hang.
+#pragma once
+
+#include "polr_mpx_device.h"
+
+#define POLR_POOL_RINGS 8
+#define POLR_POOL_HI_TUPLES 4096u // rounds up to this many tuples are latency-critical (exploration slices)
+#define POLR_POOL_HI_UNIT 64u
+#define POLR_POOL_KIND_WORK 1u
+#define POLR_POOL_KIND_EXIT 2u
+
+struct PoolRingCtl { // one 128-byte line each
+	unsigned long long lo_head, pad0[15];
+	unsigned long long lo_tail, pad1[15];
+	unsigned long long hi_head, hi_tail, pad2[14]; // (read together by the pollers)
+};
+
+struct PoolEntry {
+	unsigned long long g0, g1;
+};
+
+// Persistent object of a set of executors that run together (owned by the first multiplexer of the set).
+struct PoolSync {
+	PoolRingCtl ctl[POLR_POOL_RINGS];
+	uint32_t lo_cap, hi_cap; // entries per ring (powers of two)
+	uint32_t pad[30];
+	// followed by: PoolEntry lo[POLR_POOL_RINGS][lo_cap], PoolEntry hi[POLR_POOL_RINGS][hi_cap]
+};
+
+__device__ __forceinline__ PoolEntry *polr_pool_lo(PoolSync *s, uint32_t ring, uint32_t lo_cap) {
+	return (PoolEntry *)(s + 1) + (size_t)ring * lo_cap;
+}
+__device__ __forceinline__ PoolEntry *polr_pool_hi(PoolSync *s, uint32_t ring, uint32_t lo_cap, uint32_t hi_cap) {
+	return (PoolEntry *)(s + 1) + (size_t)POLR_POOL_RINGS * lo_cap + (size_t)ring * hi_cap;
+}
+
+// Per-run header, rewritten by the host with every launch (copied with the executor descriptors).
+struct PoolRun {
+	PoolSync *sync;
+	uint32_t n_exec;
+	uint32_t n_router_blocks;
+	uint32_t worker_waves[POLR_POOL_RINGS]; // probe waves that poll ring r (EXIT entries to publish)
+	uint32_t pool_waves;                    // all probe waves
+	uint32_t lo_cap, hi_cap;                // entries per ring (powers of two), as in *sync
+	uint32_t routers_done;                  // device: routers that have finished
+	uint32_t abort;                         // device: a watchdog fired
+	volatile uint32_t *host_words;          // pinned: [2] = 1 when the run was given up
+};
+
+__device__ __forceinline__ uint32_t polr_pool_tag(unsigned long long ticket, uint32_t cap) {
+	return (uint32_t)((ticket / cap) % 65535ull) + 1u;
+}
+
+__device__ __forceinline__ unsigned long long polr_pool_g0(uint32_t tag, uint32_t kind, uint32_t slot, uint32_t emit,
+                                                           uint32_t path, uint32_t begin) {
+	return ((unsigned long long)tag << 48) | ((unsigned long long)(kind & 3u) << 46) |
+	       ((unsigned long long)(slot & 1u) << 45) | ((unsigned long long)(emit & 1u) << 44) |
+	       ((unsigned long long)(path & 31u) << 39) | begin;
+}
+__device__ __forceinline__ unsigned long long polr_pool_g1(uint32_t tag, uint32_t exec, uint32_t count) {
+	return ((unsigned long long)tag << 48) | ((unsigned long long)(exec & 0xFFFFu) << 32) | count;
+}
+
+// what a router has decided for one round, as the publisher needs it
+struct PoolRoundOut {
+	uint32_t begin, count, path, emit, unit, n_units, hi;
+};
+
+// unit size of a round: small rounds are spread 64 tuples per wave (the dependent-load chain of a step is the same
+// for 64 and for 512 tuples: more waves in parallel is strictly faster); big rounds are cut so that one executor's
+// round gives every probe wave of its share of the pool a few units, in multiples of `gran` tuples
+__device__ __forceinline__ void polr_pool_size_units(uint64_t tuples, uint32_t pool_waves, uint32_t n_exec, uint32_t gran,
+                                                     PoolRoundOut &r) {
+	if (tuples <= POLR_POOL_HI_TUPLES) {
+		r.hi = 1;
+		r.unit = POLR_POOL_HI_UNIT;
+	} else {
+		r.hi = 0;
+		uint64_t target = 4ull * pool_waves / (n_exec ? n_exec : 1u);
+		target = target < 16 ? 16 : target;
+		uint64_t us = (tuples + target - 1) / target;
+		us = ((us + gran - 1) / gran) * gran;
+		r.unit = (uint32_t)(us < gran ? gran : (us > 0x40000000ull ? 0x40000000ull : us));
+	}
+	r.n_units = (uint32_t)((tuples + r.unit - 1) / r.unit);
+}
+
+// sum of the 8 arrival shards of a slot (full wave; the same value in every lane)
+__device__ __forceinline__ unsigned long long polr_pool_arrived(ResidentSync *sync, uint32_t slot, uint32_t lane) {
+	unsigned long long v = 0;
+	if (lane < POLR_POOL_RINGS) {
+		v = __hip_atomic_load(&sync->arrived[slot][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	for (int d = 4; d > 0; d >>= 1) {
+		v += __shfl_xor(v, d, 64);
+	}
+	return __shfl(v, 0, 64);
+}
+
+// absorb the counter bank of a slot: lane = j * 8 + shard exchanges counter j of shard `shard` with 0 (k <= 8:
+// one instruction for the whole bank).  Returns the sum of all k counters in lane 0.
+__device__ __forceinline__ uint64_t polr_pool_absorb(DevMpx *m, DevMpx *mg, unsigned long long *bank, uint32_t k,
+                                                     uint32_t lane, bool discard) {
+	const uint32_t j = lane >> 3, shard = lane & 7u;
+	unsigned long long v = 0;
+	if (j < k) {
+		v = atomicExch(&bank[(uint64_t)shard * POLR_KMAX + j], 0ull);
+	}
+	for (int d = 4; d > 0; d >>= 1) {
+		v += __shfl_xor(v, d, 64);
+	}
+	// lanes j*8 now hold counter j
+	uint64_t s = 0;
+	const uint32_t last_path = (uint32_t)((volatile DevMpx *)m)->last_path;
+	for (uint32_t jj = 0; jj < k; jj++) {
+		const unsigned long long c = __shfl(v, jj * 8, 64);
+		if (lane == 0 && !discard && c) {
+			s += c;
+			atomicAdd((unsigned long long *)&mg->stage_out[last_path][jj], c);
+		}
+	}
+	return s;
+}
+
+// publish one round: deal its units over the rings (starting at ring `rot`), lane-parallel
+__device__ __forceinline__ void polr_pool_publish(const PoolRun &run, PoolSync *sync, uint32_t exec, uint32_t slot,
+                                                  const PoolRoundOut &r, uint32_t rot, uint32_t lane) {
+	const uint32_t lo_cap = run.lo_cap, hi_cap = run.hi_cap;
+	// ring (rot + u) % 8 gets unit u: n_r units for ring r
+	unsigned long long base = 0;
+	if (lane < POLR_POOL_RINGS) {
+		const uint32_t first = (lane + POLR_POOL_RINGS - (rot & 7u)) & 7u; // smallest u dealt to ring `lane`
+		const uint32_t n_r = r.n_units > first ? (r.n_units - first + 7u) / 8u : 0u;
+		if (n_r) {
+			base = atomicAdd(r.hi ? &sync->ctl[lane].hi_tail : &sync->ctl[lane].lo_tail, (unsigned long long)n_r);
+		}
+	}
+	for (uint32_t u0 = 0; u0 < r.n_units; u0 += 64) {
+		const uint32_t u = u0 + lane;
+		const uint32_t ring = (rot + u) & 7u;
+		const unsigned long long ring_base = __shfl(base, ring, 64);
+		if (u < r.n_units) {
+			const unsigned long long ticket = ring_base + u / 8u;
+			const uint32_t cap = r.hi ? hi_cap : lo_cap;
+			PoolEntry *e = (r.hi ? polr_pool_hi(sync, ring, lo_cap, hi_cap) : polr_pool_lo(sync, ring, lo_cap)) +
+			               (ticket & (cap - 1u));
+			const uint32_t tag = polr_pool_tag(ticket, cap);
+			const uint32_t ub = r.begin + u * r.unit;
+			const uint32_t left = r.count - u * r.unit;
+			const uint32_t uc = left < r.unit ? left : r.unit;
+			__hip_atomic_store(&e->g1, polr_pool_g1(tag, exec, uc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&e->g0, polr_pool_g0(tag, POLR_POOL_KIND_WORK, slot, r.emit, r.path, ub), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+// one EXIT entry per probe wave of every ring (the router that finishes last)
+__device__ __forceinline__ void polr_pool_publish_exit(const PoolRun &run, PoolSync *sync, uint32_t lane) {
+	const uint32_t lo_cap = run.lo_cap;
+	for (uint32_t ring = 0; ring < POLR_POOL_RINGS; ring++) {
+		const uint32_t n = run.worker_waves[ring];
+		if (n == 0) {
+			continue;
+		}
+		unsigned long long base = 0;
+		if (lane == 0) {
+			base = atomicAdd(&sync->ctl[ring].lo_tail, (unsigned long long)n);
+		}
+		base = __shfl(base, 0, 64);
+		for (uint32_t i = lane; i < n; i += 64) {
+			const unsigned long long ticket = base + i;
+			PoolEntry *e = polr_pool_lo(sync, ring, lo_cap) + (ticket & (lo_cap - 1u));
+			const uint32_t tag = polr_pool_tag(ticket, lo_cap);
+			__hip_atomic_store(&e->g1, polr_pool_g1(tag, 0, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&e->g0, polr_pool_g0(tag, POLR_POOL_KIND_EXIT, 0, 0, 0, 0), __ATOMIC_RELAXED,
+			                   __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+// ---- worker side ---------------------------------------------------------------------------------
+struct PoolUnit {
+	uint32_t kind, slot, emit, path, exec, begin, count;
+};
+
+__device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned long long g1, uint32_t tag, PoolUnit &u) {
+	if ((uint32_t)(g0 >> 48) != tag || (uint32_t)(g1 >> 48) != tag) {
+		return false;
+	}
+	u.kind = (uint32_t)(g0 >> 46) & 3u;
+	u.slot = (uint32_t)(g0 >> 45) & 1u;
+	u.emit = (uint32_t)(g0 >> 44) & 1u;
+	u.path = (uint32_t)(g0 >> 39) & 31u;
+	u.begin = (uint32_t)g0;
+	u.exec = (uint32_t)(g1 >> 32) & 0xFFFFu;
+	u.count = (uint32_t)g1;
+	return true;
+}
+
+// Take the next unit for this wave (all lanes get the same answer).  lo_ticket: the lo ticket this wave holds
+// (~0ull: none) -- kept across calls, because a wave that holds a not-yet-written lo ticket serves hi units meanwhile.
+// Returns false when the wave has to leave (EXIT entry, abort or watchdog).
+__device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run, PoolSync *sync, uint32_t ring, uint32_t lo_cap,
+                                                    uint32_t hi_cap, unsigned long long &lo_ticket, PoolUnit &u,
+                                                    uint32_t lane) {
+	PoolRingCtl *ctl = &sync->ctl[ring];
+	uint32_t spins = 0;
+	while (true) {
+		unsigned long long g0 = 0, g1 = 0;
+		uint32_t tag = 0, got = 0;
+		if (lane == 0) {
+			// (1) latency-critical units first: only while the hi queue is not empty, never blocking
+			const unsigned long long hh = __hip_atomic_load(&ctl->hi_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long ht = __hip_atomic_load(&ctl->hi_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (hh < ht) {
+				unsigned long long expect = hh;
+				if (__hip_atomic_compare_exchange_strong(&ctl->hi_head, &expect, hh + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+				                                         __HIP_MEMORY_SCOPE_AGENT)) {
+					// ticket hh is ours; its entry is being written by the router that reserved it
+					PoolEntry *e = polr_pool_hi(sync, ring, lo_cap, hi_cap) + (hh & (hi_cap - 1u));
+					tag = polr_pool_tag(hh, hi_cap);
+					const unsigned long long t1 = wall_clock64();
+					while (true) {
+						g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) ||
+						    wall_clock64() - t1 > POLR_RES_TIMEOUT_TICKS) {
+							break;
+						}
+						__builtin_amdgcn_s_sleep(1);
+					}
+					got = 1;
+				}
+			}
+			if (!got) {
+				// (2) the lo queue: hold one ticket, look whether its entry has been written
+				if (lo_ticket == ~0ull) {
+					lo_ticket = atomicAdd(&ctl->lo_head, 1ull);
+				}
+				PoolEntry *e = polr_pool_lo(sync, ring, lo_cap) + (lo_ticket & (lo_cap - 1u));
+				tag = polr_pool_tag(lo_ticket, lo_cap);
+				g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) {
+					got = 2;
+					lo_ticket = ~0ull;
+				}
+			}
+		}
+		got = __builtin_amdgcn_readfirstlane(got);
+		if (got) {
+			g0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g0 >> 32)) << 32) |
+			     __builtin_amdgcn_readfirstlane((uint32_t)g0);
+			g1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g1 >> 32)) << 32) |
+			     __builtin_amdgcn_readfirstlane((uint32_t)g1);
+			tag = __builtin_amdgcn_readfirstlane(tag);
+			if (!polr_pool_decode(g0, g1, tag, u)) {
+				return false; // (a hi entry that never arrived: watchdog)
+			}
+			return u.kind == POLR_POOL_KIND_WORK;
+		}
+		// nothing yet: back off (longer the longer nothing comes), give up when the run was given up
+		spins++;
+		if (spins < 16) {
+			__builtin_amdgcn_s_sleep(2);
+		} else {
+			__builtin_amdgcn_s_sleep(16);
+		}
+		if ((spins & 15u) == 0) {
+			// (no clock of its own: an idle wave may wait as long as the run takes; the routers' waits are bounded,
+			// they raise `abort`, and the last of them always publishes the EXIT entries)
+			uint32_t ab = 0;
+			if (lane == 0) {
+				ab = __hip_atomic_load(&run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (__builtin_amdgcn_readfirstlane(ab)) {
+				return false;
+			}
+		}
+	}
+}
+
+// ---- the router of one executor: ONE full wave, for the whole run ----------------------------------
+// lds: POLR_RES_ROUTER_DWORDS dwords of state + scratch_lds: POLR_RES_HOT_DWORDS dwords (saved state of a rehearsal);
+// cache_lds / cache_cap: window of the chunk-offset array in 8-byte entries.
+__device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun *run, const PoolRun &rh, uint32_t exec,
+                                                 uint32_t k, uint32_t gran, uint32_t lane, uint32_t *lds,
+                                                 uint64_t *cache_lds, uint32_t cache_cap, uint32_t *scratch_lds) {
+	DevMpx *mg = x.mpx;
+	PoolSync *sync = rh.sync;
+	const bool reset = (x.flags & POLR_RUN_RESET) != 0;
+	const size_t bank_stride = (size_t)POLR_NSHARD * POLR_KMAX;
+	if (reset) {
+		// drop whatever bank 0 still holds (fire and forget; performed long before the first round is absorbed)
+		const uint32_t j = lane >> 3;
+		if (j < k) {
+			(void)atomicExch(&x.counts[(uint64_t)(lane & 7u) * POLR_KMAX + j], 0ull);
+		}
+	}
+	{
+		const uint32_t *src = (const uint32_t *)mg;
+		constexpr uint32_t kPer = (POLR_RES_HOT_DWORDS + 63) / 64;
+		uint32_t v[kPer];
+#pragma unroll
+		for (uint32_t j = 0; j < kPer; j++) {
+			const uint32_t i = j * 64 + lane;
+			v[j] = i < POLR_RES_HOT_DWORDS ? src[i] : 0u;
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < kPer; j++) {
+			const uint32_t i = j * 64 + lane;
+			if (i < POLR_RES_HOT_DWORDS) {
+				lds[i] = v[j];
+			}
+		}
+	}
+	DevMpx *m = (DevMpx *)lds;
+	volatile uint32_t *const host_words = mg->progress;
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		m->progress = nullptr; // nobody on the host follows the steps of a one-launch run
+	}
+	DevRound *round = (DevRound *)(lds + POLR_RES_HOT_DWORDS); // 24 bytes
+	uint64_t *prefix = (uint64_t *)(lds + POLR_RES_HOT_DWORDS + 8);
+	uint32_t *us = lds + POLR_RES_HOT_DWORDS + 12;
+	OffsCache oc;
+	oc.base = 0;
+	oc.n = 0;
+	oc.data = cache_lds;
+	if (cache_cap > POLR_OFFS_CACHE) {
+		cache_cap = POLR_OFFS_CACHE;
+	}
+	if (reset) {
+		for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
+			mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = 0;
+		}
+		if (lane == 0) {
+			const polr_mpx_config cfg = m->cfg;
+			m->core.Init(cfg.routing, m->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
+			m->num_intermediates_total = 0;
+			m->num_rounds = 0;
+			m->n_log = 0;
+			m->last_path = 0;
+		}
+	}
+	if (lane == 0) {
+		m->chunk_idx = x.morsel_cursor ? 0 : x.chunk_begin;
+		m->chunk_end = x.morsel_cursor ? 0 : x.chunk_end;
+		m->chunk_offsets = x.chunk_offsets;
+		m->n_chunks = x.n_chunks;
+		m->n_tuples = x.n_tuples;
+		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
+	}
+	__builtin_amdgcn_wave_barrier();
+	unsigned long long target[2];
+	if (((volatile DevMpx *)m)->res_valid) {
+		target[0] = ((volatile DevMpx *)m)->res_target[0];
+		target[1] = ((volatile DevMpx *)m)->res_target[1];
+	} else {
+		target[0] = polr_pool_arrived(x.sync, 0, lane);
+		target[1] = polr_pool_arrived(x.sync, 1, lane);
+		polr_pool_absorb(m, mg, x.counts + bank_stride, k, lane, true);
+	}
+	uint32_t n_steps = 0;
+	uint32_t n_pub = 0;        // rounds published so far: the next one goes to slot n_pub & 1
+	bool have_pending = false; // a published round whose counters have not been absorbed yet ...
+	uint32_t pend_slot = 0;    // ... in this slot
+	bool have_spec = false;    // the round after it is published too (speculated), kept for the check
+	PoolRoundOut spec = {};
+	bool failed = false;
+	uint32_t rot = exec; // units of consecutive rounds start on different rings
+	while (true) {
+		__builtin_amdgcn_wave_barrier();
+		// (1) the oldest round in flight has to be complete before its counters can be absorbed
+		if (have_pending) {
+			const unsigned long long t0 = wall_clock64();
+			uint32_t spins = 0;
+			while (polr_pool_arrived(x.sync, pend_slot, lane) != target[pend_slot]) {
+				__builtin_amdgcn_s_sleep(1);
+				if ((++spins & 63u) == 0) {
+					uint32_t ab = __hip_atomic_load(&run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (ab || wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
+						failed = true; // a probe wave is missing
+						break;
+					}
+				}
+			}
+			if (failed) {
+				break;
+			}
+		}
+		// (2) the real step
+		if (!(reset && n_steps == 0)) { // (a reset run starts on the bank it dropped at entry)
+			const uint64_t got =
+			    polr_pool_absorb(m, mg, x.counts + (have_pending ? pend_slot : 0u) * bank_stride, k, lane, false);
+			if (lane == 0) {
+				m->core.AddNumIntermediates(got);
+				m->num_intermediates_total += got;
+			}
+		}
+		if (lane == 0 && x.morsel_cursor && m->chunk_idx >= m->chunk_end) {
+			// this executor's morsel is used up (or it has none yet): pull the next one
+			const unsigned long long next = atomicAdd(x.morsel_cursor, (unsigned long long)x.morsel_chunks);
+			if (next < x.morsel_end) {
+				m->chunk_idx = next;
+				m->chunk_end = next + x.morsel_chunks < x.morsel_end ? next + x.morsel_chunks : x.morsel_end;
+				m->done = 0;
+			}
+		}
+		n_steps++;
+		// Two passes over ONE inlined copy of the routing code: pass 0 is the real step on the state, pass 1 -- only
+		// if the decision after it cannot depend on the intermediates of the round just routed -- rehearses the
+		// next step on a copy and publishes it in the other slot.
+		bool stop = false;
+		for (uint32_t pass = 0; pass < 2 && !stop; pass++) {
+			__builtin_amdgcn_wave_barrier();
+			if (pass == 1) {
+				if (have_spec || !polr_can_speculate(((volatile DevMpx *)m)->core)) {
+					break;
+				}
+				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+					scratch_lds[i] = lds[i];
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) {
+					m->log_enabled = 0; // (no trace of the rehearsal)
+				}
+			}
+			if (lane == 0) {
+				polr_router_route(m, round, prefix, us, rh.pool_waves, &oc);
+			}
+			__builtin_amdgcn_wave_barrier();
+			const bool done = ((volatile DevMpx *)m)->done != 0;
+			const volatile DevRound *vr = round;
+			PoolRoundOut r;
+			r.begin = (uint32_t)vr->begin;
+			r.count = (uint32_t)vr->count;
+			r.path = vr->path;
+			r.emit = vr->emit;
+			polr_pool_size_units(r.count, rh.pool_waves, rh.n_exec, gran, r);
+			if (pass == 1) {
+				__builtin_amdgcn_wave_barrier();
+				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+					lds[i] = scratch_lds[i];
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			if (pass == 0 && have_spec) {
+				// this round is already out: the real decision must be the speculated one, bit for bit
+				if (done || r.begin != spec.begin || r.count != spec.count || r.path != spec.path || r.emit != spec.emit) {
+					failed = true; // (cannot happen while polr_can_speculate is right; never continue on a wrong round)
+					stop = true;
+					break;
+				}
+				have_spec = false;
+				pend_slot ^= 1u;
+				continue;
+			}
+			if (done) {
+				if (pass == 0) {
+					stop = true;
+				}
+				break; // (a rehearsal that runs off the end of the source publishes nothing)
+			}
+			const uint32_t slot = n_pub & 1u;
+			polr_pool_publish(rh, sync, exec, slot, r, rot, lane);
+			rot += r.n_units;
+			target[slot] += r.n_units;
+			n_pub++;
+			if (pass == 0) {
+				pend_slot = slot;
+				have_pending = true;
+			} else {
+				have_spec = true;
+				spec = r;
+			}
+		}
+		if (stop) {
+			break;
+		}
+		// while the pool probes: keep the boundaries of the chunks ahead in LDS
+		{
+			const uint64_t ci = ((volatile DevMpx *)m)->chunk_idx;
+			if (x.chunk_offsets && ci - oc.base >= oc.n / 2) { // (also the first fill: n == 0)
+				polr_offs_cache_fill(oc, x, ci, cache_cap, lane);
+			}
+		}
+	}
+	if (failed) {
+		if (lane == 0) {
+			__hip_atomic_store(&run->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (host_words) {
+				host_words[2] = 1;
+			}
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (x.flags & POLR_RUN_FINISH) {
+		if (lane == 0) {
+			polr_close_run(m);
+		}
+		__builtin_amdgcn_wave_barrier();
+		polr_write_stats(m, mg, x.stats_out, lane);
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		m->res_valid = failed ? 0u : 1u;
+		m->res_target[0] = target[0];
+		m->res_target[1] = target[1];
+		m->progress = host_words;
+		if (host_words) { // what a per-round run would have published: the run is over
+			host_words[1] = m->done;
+			host_words[0] = m->steps_done;
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	{
+		uint32_t *dst = (uint32_t *)mg;
+		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+			dst[i] = lds[i];
+		}
+	}
+	// the router that finishes last lets the pool go
+	uint32_t last = 0;
+	if (lane == 0) {
+		const uint32_t before = atomicAdd(&run->routers_done, 1u);
+		last = before + 1u == rh.n_exec ? 1u : 0u;
+	}
+	if (__builtin_amdgcn_readfirstlane(last)) {
+		polr_pool_publish_exit(rh, sync, lane);
+	}
+}

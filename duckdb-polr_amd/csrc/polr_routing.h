@@ -12,7 +12,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define POLR_HD __host__ __device__
 #else
 #define POLR_HD

@@ -266,6 +266,7 @@ extern "C" {
 
 int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_filter *filters, uint32_t n_filters,
                               uint32_t vector_size, uint64_t *n_selected, uint64_t *n_chunks) {
+	POLR_ENTRY();
 	if (!p || (!filters && n_filters)) {
 		return POLR_E_INVALID;
 	}
@@ -394,6 +395,7 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 }
 
 int polr_pipeline_fetch_scan(polr_pipeline *p, uint32_t *sel, uint64_t *chunk_offsets) {
+	POLR_ENTRY();
 	if (!p) {
 		return POLR_E_INVALID;
 	}

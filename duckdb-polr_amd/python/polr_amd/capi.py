@@ -74,7 +74,7 @@ AGG = {"count_star": 0, "count": 1, "sum": 2, "min": 3, "max": 4}
 
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("waves_per_workgroup", "workgroups_per_cu", "lds_bytes_per_workgroup",
-                                          "compiled_stages", "tuple_slots", "n_cus")]
+                                          "compiled_stages", "tuple_slots", "n_cus", "flat", "lds_tables", "lds_table_bytes", "pad")]
 
 
 class GroupKey(C.Structure):

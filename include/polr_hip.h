@@ -170,6 +170,10 @@ int polr_pipeline_set_selection(polr_pipeline *p, const uint32_t *sel, uint64_t 
  * materialize != 0: the variant that writes row ids (an `out` object is passed to the runs). */
 typedef struct polr_launch_info {
 	uint32_t waves_per_workgroup, workgroups_per_cu, lds_bytes_per_workgroup, compiled_stages, tuple_slots, n_cus;
+	uint32_t flat;            /* 1: counting runs use the flat pipeline (single-key unique-match joins on probe columns) */
+	uint32_t lds_tables;      /* bit tables kept in LDS for the whole run */
+	uint32_t lds_table_bytes;
+	uint32_t pad;
 } polr_launch_info;
 int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_info *info);
 
