@@ -19,6 +19,19 @@ struct JoinCondition {
 	bool left_is_bound_ref = true;
 };
 
+// What SelSampleEnumeration reads off the plan below a join (JoinOrderNode, polar_enumeration_algo.hpp:72-83, filled by
+// ExtractInfoLinear polar_enumeration_algo.cpp:190-246): the scanned base table's cardinality
+// (DataTableInfo::cardinality, exact), whether the scan carries pushed-down table filters or sits under a FILTER
+// (`predicate`), and whether a UNIQUE / PRIMARY KEY constraint covers a scanned column (`unique`).  The host mirror has no
+// plan trees: the engine that owns them fills these in when it creates the operator.  nested = the build side is itself
+// a join tree (the reference recurses into it; not mirrored: SAMPLE throws).
+struct JoinOrderNodeInfo {
+	idx_t base_table_card = 0;
+	bool predicate = false;
+	bool unique = false;
+	bool nested = false;
+};
+
 struct PerfectHashJoinStats {
 	bool is_build_small = false; // plan_comparison_join.cpp:63-133
 	int64_t build_min = 0, build_max = 0;
@@ -38,6 +51,8 @@ public:
 	vector<idx_t> right_projection_map;
 	PerfectHashJoinStats perfect_join_statistics;
 	idx_t uncertainty_level = 1; // what UncertainCardinalitySelector's plan walk would return
+	JoinOrderNodeInfo build_side_info;   // children[1] of this join, for SelSampleEnumeration
+	JoinOrderNodeInfo probe_source_info; // the pipeline's source below the join run (read from the FIRST join of the run)
 
 	// ---- sink side, reduced to what the probe needs: hand the build columns over once -------------
 	// (PhysicalHashJoin::Sink/Finalize physical_hash_join.cpp:217-286,337-481 -> HBM residency)

@@ -117,4 +117,24 @@ bool POLARConfig::GenerateJoinOrders() {
 	return true;
 }
 
+std::unique_ptr<POLARConfig> MakePolarConfigForPipeline(ClientContext &context, JoinList joins,
+                                                        idx_t source_estimated_cardinality) {
+	std::unique_ptr<POLARConfig> polar(new POLARConfig(context, joins, source_estimated_cardinality,
+	                                                   JoinEnumerationAlgo::CreateEnumerationAlgo(context)));
+	bool generated = polar->GenerateJoinOrders();
+	if (!generated && context.config.join_enumerator != JoinEnumerator::BFS_MIN_CARD) {
+		polar.reset(new POLARConfig(context, joins, source_estimated_cardinality,
+		                            unique_ptr<JoinEnumerationAlgo>(new BFSEnumeration(
+		                                unique_ptr<CandidateSelector>(new MinCardinalitySelector())))));
+		generated = polar->GenerateJoinOrders();
+		if (generated) {
+			polar->multiplexer->routing = MultiplexerRouting::DEFAULT_PATH;
+		}
+	}
+	if (!generated) {
+		return nullptr;
+	}
+	return polar;
+}
+
 } // namespace duckdb_polr

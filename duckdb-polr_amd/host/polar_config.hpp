@@ -48,4 +48,11 @@ public:
 	double enumeration_time_ms = 0;
 };
 
+// The POLAR part of Pipeline::Ready (src/parallel/pipeline.cpp:213-232): the configured enumerator first; if it finds
+// fewer than two orders and is not BFS_MIN_CARD itself, BFS + MinCardinality (max_join_orders at its default of 24) is
+// tried and -- when that finds a bank -- the multiplexer routes DEFAULT_PATH, so that intermediates are still counted
+// ("to enable comparing enumerators").  nullptr: POLAR does not apply to this run of joins.
+std::unique_ptr<POLARConfig> MakePolarConfigForPipeline(ClientContext &context, JoinList joins,
+                                                        idx_t source_estimated_cardinality);
+
 } // namespace duckdb_polr

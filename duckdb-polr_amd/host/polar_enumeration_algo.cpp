@@ -46,6 +46,11 @@ idx_t UncertainCardinalitySelector::SelectNextCandidate(const JoinOrder &candida
 
 // The enumerator the session asks for (reference behaviour: polar_enumeration_algo.cpp:79-124)
 unique_ptr<JoinEnumerationAlgo> JoinEnumerationAlgo::CreateEnumerationAlgo(ClientContext &context) {
+	if (context.config.join_enumerator == JoinEnumerator::SAMPLE) {
+		unique_ptr<JoinEnumerationAlgo> sample(new SelSampleEnumeration());
+		sample->max_join_orders = context.config.max_join_orders;
+		return sample;
+	}
 	enum class Walk { DEPTH, BREADTH, LAST_ONCE, FIRST_ONCE };
 	enum class Pick { NONE, RANDOM, MIN_CARD, UNCERTAIN };
 	Walk walk;
@@ -59,13 +64,6 @@ unique_ptr<JoinEnumerationAlgo> JoinEnumerationAlgo::CreateEnumerationAlgo(Clien
 	case JoinEnumerator::BFS_UNCERTAIN:   walk = Walk::BREADTH; pick = Pick::UNCERTAIN; break;
 	case JoinEnumerator::EACH_LAST_ONCE:  walk = Walk::LAST_ONCE;  break;
 	case JoinEnumerator::EACH_FIRST_ONCE: walk = Walk::FIRST_ONCE; break;
-	case JoinEnumerator::SAMPLE:
-		// SelSampleEnumeration (:370-556) samples selectivities with libstdc++'s mt19937(1337) stream over
-		// plan-tree statistics the host mirror does not carry; Pipeline::Ready's own fallback when an enumerator
-		// yields < 2 orders is BFS_MIN_CARD (pipeline.cpp:216-225) -- used here directly.
-		walk = Walk::BREADTH;
-		pick = Pick::MIN_CARD;
-		break;
 	default:
 		throw InternalException("unknown join enumerator");
 	}
@@ -105,6 +103,16 @@ bool JoinEnumerationAlgo::CanJoin(vector<idx_t> &r, idx_t s, DependencyMap &depe
 		}
 	}
 	return true;
+}
+
+// :137-145
+bool JoinEnumerationAlgo::CanJoin(vector<idx_t> &r, vector<idx_t> &s, DependencyMap &dependencies) {
+	for (auto &si : s) {
+		if (CanJoin(r, si, dependencies)) {
+			return true;
+		}
+	}
+	return false;
 }
 
 // :137-150: just the default join order
@@ -309,6 +317,210 @@ void BFSEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
 		}
 	}
 	MoveOriginalOrderFirst(join_orders, hash_join_idxs.size(), max_join_orders);
+}
+
+// ---- SelSampleEnumeration ------------------------------------------------------------------------------------
+// GenerateQuantifierSets (:289-321): the r-subsets of {0..n-1} in lexicographic order
+static void QuantifierSets(idx_t n, idx_t r, idx_t first, vector<idx_t> &cur, vector<vector<idx_t>> &out) {
+	if (cur.size() == r) {
+		out.push_back(cur);
+		return;
+	}
+	for (idx_t i = first; i < n; i++) {
+		cur.push_back(i);
+		QuantifierSets(n, r, i + 1, cur, out);
+		cur.pop_back();
+	}
+}
+
+// :332-390
+SelSampleEnumeration::NodeSeq SelSampleEnumeration::DpSize(const vector<JoinOrderNodeInfo> &initial_join_order,
+                                                           DependencyMap &dependencies) {
+	vector<idx_t> empty;
+	const idx_t n = initial_join_order.size() - 1; // the joins
+	NodeSet join_nodes;
+	for (idx_t i = 1; i <= n; i++) {
+		join_nodes.insert(i);
+		if (CanJoin(empty, i - 1, dependencies)) {
+			best_plans[NodeSet {i}] = NodeSeq {0, i};
+		}
+	}
+	for (idx_t s = 1; s < n; s++) {
+		vector<vector<idx_t>> qsets;
+		vector<idx_t> cur;
+		QuantifierSets(n, s, 0, cur, qsets);
+		for (auto &p_s1 : qsets) {
+			for (idx_t p_s2 = 0; p_s2 < n; p_s2++) {
+				if (std::find(p_s1.begin(), p_s1.end(), p_s2) != p_s1.end()) {
+					continue; // !Disjoint
+				}
+				if (!CanJoin(empty, p_s1, dependencies) || !CanJoin(p_s1, p_s2, dependencies)) {
+					continue;
+				}
+				NodeSet new_set;
+				for (auto idx : p_s1) {
+					new_set.insert(idx + 1);
+				}
+				auto found = best_plans.find(new_set);
+				if (found == best_plans.cend()) {
+					continue;
+				}
+				NodeSeq new_plan = found->second;
+				new_set.insert(p_s2 + 1);
+				new_plan.push_back(p_s2 + 1);
+				auto best_plan = best_plans.find(new_set);
+				if (best_plan != best_plans.cend()) {
+					// (which plan is costed first decides which one draws its selectivities first: part of the stream)
+					const bool calc_new_plan_first = std::round(dist(rng)) != 0;
+					double c_new, c_best;
+					if (calc_new_plan_first) {
+						c_new = CalculateCost(new_plan);
+						c_best = CalculateCost(best_plan->second);
+					} else {
+						c_best = CalculateCost(best_plan->second);
+						c_new = CalculateCost(new_plan);
+					}
+					if (c_new < c_best) {
+						best_plans[new_set] = new_plan;
+					}
+				} else {
+					best_plans[new_set] = new_plan;
+				}
+			}
+		}
+	}
+	return best_plans[join_nodes];
+}
+
+// :404-483.  join_order.front() is always the source.  Kept as the reference has it, including the cast that binds
+// before the multiplication in the last branch (`SEL_STEPS[(idx_t) rand * SEL_STEPS.size()]` is SEL_STEPS[0], :464).
+double SelSampleEnumeration::CalculateCost(const NodeSeq &join_order) {
+	auto entry = cost_map.find(join_order);
+	if (entry != cost_map.cend()) {
+		return entry->second;
+	}
+	const vector<JoinOrderNodeInfo> &N = *nodes;
+	if (join_order.size() == 1) {
+		const JoinOrderNodeInfo &node = N[join_order.front()];
+		double card = (double)node.base_table_card;
+		if (node.predicate) {
+			auto rand = dist(rng);
+			auto sel = SEL_STEPS[(idx_t)(rand * SEL_STEPS.size())] + rand * SEL_STEPS[0];
+			card *= sel;
+		}
+		card_map[NodeSet(join_order.cbegin(), join_order.cend())] = card;
+		cost_map[join_order] = 0;
+	} else {
+		NodeSet lhs(join_order.cbegin(), join_order.cend() - 1);
+		NodeSeq lhs_ordered(join_order.begin(), join_order.cend() - 1);
+		NodeSet rhs {join_order.back()};
+		NodeSet new_set = lhs;
+		new_set.insert(join_order.back());
+		if (card_map.find(lhs) == card_map.cend()) {
+			CalculateCost(lhs_ordered);
+		}
+		if (card_map.find(rhs) == card_map.cend()) {
+			CalculateCost(NodeSeq {join_order.back()});
+		}
+		double card = card_map[lhs];
+		// GetJoinsWithPredicate (:392-402): the relations of the new set that carry a predicate, plus the source
+		NodeSet lhs_predicates_only;
+		for (auto node : new_set) {
+			if (N[node].predicate) {
+				lhs_predicates_only.insert(node);
+			}
+		}
+		lhs_predicates_only.insert(join_order.front());
+		if (card_map.find(new_set) != card_map.cend()) {
+			card = card_map[new_set];
+		} else if (card_map.find(lhs_predicates_only) != card_map.cend()) {
+			card = card_map[lhs_predicates_only];
+		} else if (N[join_order.back()].unique) {
+			// the largest cardinality already fixed for a superset bounds this one from below
+			double min_card = 0;
+			for (auto &card_entry : card_map) {
+				if (card_entry.first.size() > new_set.size()) {
+					bool is_superset = true;
+					for (auto node : new_set) {
+						if (card_entry.first.find(node) == card_entry.first.cend()) {
+							is_superset = false;
+						}
+					}
+					if (!is_superset) {
+						continue;
+					}
+					min_card = card_entry.second > min_card ? card_entry.second : min_card;
+				}
+			}
+			if (N[join_order.back()].predicate) {
+				auto rand = dist(rng);
+				auto sel = SEL_STEPS[(idx_t)(rand * SEL_STEPS.size())] + rand * SEL_STEPS[0];
+				card = min_card + sel * (card - min_card);
+			}
+		} else {
+			auto rand = dist(rng);
+			auto sel = SEL_STEPS[(idx_t)rand * SEL_STEPS.size()] + rand * SEL_STEPS[0];
+			card *= card_map[rhs] * sel;
+		}
+		card_map[new_set] = card;
+		cost_map[join_order] = cost_map[lhs_ordered] + card;
+	}
+	return cost_map[join_order];
+}
+
+static idx_t Factorial(idx_t i) {
+	return i <= 1 ? 1 : i * Factorial(i - 1);
+}
+
+// :492-556
+void SelSampleEnumeration::GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
+                                              const JoinList &joins, vector<JoinOrder> &join_orders) {
+	const idx_t SAMPLE_COUNT = max_join_orders;
+	// CreateJoinOrderNodes (:248-287): the source, then the build side of every join
+	vector<JoinOrderNodeInfo> node_infos;
+	node_infos.push_back(joins.front()->probe_source_info);
+	for (auto *join : joins) {
+		node_infos.push_back(join->build_side_info);
+	}
+	for (auto &ni : node_infos) {
+		if (ni.nested) {
+			throw NotImplementedException("SelSampleEnumeration over a nested join tree");
+		}
+	}
+	nodes = &node_infos;
+	idx_t rhs_relations_with_predicate = 0;
+	for (idx_t i = 1; i < node_infos.size(); i++) {
+		if (node_infos[i].predicate || !node_infos[i].unique) {
+			rhs_relations_with_predicate++;
+		}
+	}
+	const idx_t max_unique_join_orders = Factorial(rhs_relations_with_predicate);
+	std::set<vector<idx_t>> unique_join_orders;
+	vector<idx_t> inital_join_order(joins.size());
+	std::iota(inital_join_order.begin(), inital_join_order.end(), 0);
+	unique_join_orders.insert(inital_join_order);
+	for (idx_t i = 0; i < SAMPLE_COUNT; i++) {
+		if (unique_join_orders.size() == max_unique_join_orders) {
+			break;
+		}
+		auto join_nodes = DpSize(node_infos, dependencies);
+		if (join_nodes.size() != joins.size() + 1) {
+			throw InternalException("SelSampleEnumeration: no complete join order (dependencies cannot be met)");
+		}
+		vector<idx_t> join_order(join_nodes.size() - 1);
+		for (idx_t j = 1; j < join_nodes.size(); j++) {
+			join_order[j - 1] = join_nodes[j] - 1; // node id = join index
+		}
+		unique_join_orders.insert(join_order);
+		cost_map.clear();
+		card_map.clear();
+		best_plans.clear();
+	}
+	unique_join_orders.erase(inital_join_order);
+	join_orders.reserve(unique_join_orders.size() + 1);
+	join_orders.push_back(inital_join_order);
+	join_orders.insert(join_orders.cend(), unique_join_orders.cbegin(), unique_join_orders.cend());
+	nodes = nullptr;
 }
 
 } // namespace duckdb_polr

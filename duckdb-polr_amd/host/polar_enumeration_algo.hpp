@@ -4,6 +4,9 @@
 // routes over.  Path 0 is always the optimizer's original order.
 #pragma once
 
+#include <map>
+#include <random>
+#include <set>
 #include <unordered_map>
 
 #include "physical_hash_join.hpp"
@@ -51,8 +54,35 @@ public:
 	                                DependencyMap &dependencies,
 	                                const JoinList &joins, vector<JoinOrder> &join_orders);
 	bool CanJoin(vector<idx_t> &r, idx_t s, DependencyMap &dependencies);
+	bool CanJoin(vector<idx_t> &r, vector<idx_t> &s, DependencyMap &dependencies); // ANY of s may follow r (:137-145)
 	static unique_ptr<JoinEnumerationAlgo> CreateEnumerationAlgo(ClientContext &context);
 	idx_t max_join_orders = 24;
+};
+
+// SelSampleEnumeration (polar_enumeration_algo.hpp:85-100, polar_enumeration_algo.cpp:323-556) -- the reference's
+// DEFAULT enumerator (client_config.hpp:90): max_join_orders rounds of DPsize over the joins, each round with freshly
+// SAMPLED selectivities for the relations that carry a predicate, so that every round may crown a different order; the
+// bank = the original order + the distinct winners, in lexicographic order.  Randomness: std::mt19937(1337) through
+// std::uniform_real_distribution<double> -- the same libstdc++ classes here, hence the same stream.  Nodes are
+// identified by their position (0 = the pipeline's source, 1 + j = join j): the reference keys its maps by node
+// POINTERS into one contiguous vector, which order the same way.
+class SelSampleEnumeration : public JoinEnumerationAlgo {
+public:
+	using NodeSet = std::set<idx_t>;
+	using NodeSeq = vector<idx_t>;
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
+	                        vector<JoinOrder> &join_orders) override;
+	NodeSeq DpSize(const vector<JoinOrderNodeInfo> &nodes, DependencyMap &dependencies);
+	double CalculateCost(const NodeSeq &join_order);
+
+private:
+	const vector<JoinOrderNodeInfo> *nodes = nullptr;
+	std::map<NodeSeq, double> cost_map;
+	std::map<NodeSet, double> card_map;
+	std::map<NodeSet, NodeSeq> best_plans;
+	std::mt19937 rng = std::mt19937(1337);
+	std::uniform_real_distribution<double> dist;
+	const vector<double> SEL_STEPS = {0.0001, 0.001, 0.01, 0.1, 0.2, 0.4, 0.8};
 };
 
 class DFSEnumeration : public JoinEnumerationAlgo {

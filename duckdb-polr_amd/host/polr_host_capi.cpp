@@ -154,9 +154,27 @@ void polr_host_join_path_weights(const double *costs, int n, double regret_budge
 // cond_left_index[j*2 + c]: BoundReference index of condition c of join j in the original pipeline
 // layout (probe columns, then each join's build columns).  bindings[(p*k + j)*2 + c] = rebound column or -1.
 // returns the number of join orders, 0 when POLAR does not engage, -1 on error
+// node_card / node_flags [k + 1] (may be NULL): what SelSampleEnumeration reads off the plan -- entry 0 = the
+// pipeline's source, entry 1 + j = the build side of join j; flags bit 0 = predicate, bit 1 = unique
+int polr_host_generate_join_orders_ex(int enumerator, int routing, int k, int n_probe_cols, const int32_t *n_build_cols,
+                                      const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
+                                      int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies,
+                                      const uint64_t *node_card, const uint8_t *node_flags, int32_t *routing_out);
+
 int polr_host_generate_join_orders(int enumerator, int routing, int k, int n_probe_cols, const int32_t *n_build_cols,
                                    const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
                                    int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies) {
+	return polr_host_generate_join_orders_ex(enumerator, routing, k, n_probe_cols, n_build_cols, n_conds, cond_left_index,
+	                                         est_card, max_join_orders, paths, bindings, dependencies, nullptr, nullptr,
+	                                         nullptr);
+}
+
+int polr_host_generate_join_orders_ex(int enumerator, int routing, int k, int n_probe_cols, const int32_t *n_build_cols,
+                                      const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
+                                      int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies,
+                                      const uint64_t *node_card, const uint8_t *node_flags, int32_t *routing_out) {
+	// routing_out (may be NULL): the routing the multiplexer ends up with -- DEFAULT_PATH when only Pipeline::Ready's
+	// BFS_MIN_CARD fallback found a bank (pipeline.cpp:216-225); paths must hold 26 rows in that case (24 + 2)
 	try {
 		ClientContext client;
 		client.config.join_enumerator = (JoinEnumerator)enumerator;
@@ -167,9 +185,29 @@ int polr_host_generate_join_orders(int enumerator, int routing, int k, int n_pro
 		for (auto &j : joins) {
 			raw.push_back(j.get());
 		}
-		POLARConfig polar(client, raw, 0, JoinEnumerationAlgo::CreateEnumerationAlgo(client));
-		if (!polar.GenerateJoinOrders()) {
+		if (node_card && node_flags) {
+			auto info = [&](int i) {
+				JoinOrderNodeInfo ni;
+				ni.base_table_card = node_card[i];
+				ni.predicate = (node_flags[i] & 1) != 0;
+				ni.unique = (node_flags[i] & 2) != 0;
+				return ni;
+			};
+			raw.front()->probe_source_info = info(0);
+			for (int j = 0; j < k; j++) {
+				raw[j]->build_side_info = info(1 + j);
+			}
+		} else if ((JoinEnumerator)enumerator == JoinEnumerator::SAMPLE) {
+			throw InternalException("join_enumerator 'sample' needs the base-table cardinalities / predicate / unique "
+			                            "flags of the source and of every build side");
+		}
+		std::unique_ptr<POLARConfig> polar_p = MakePolarConfigForPipeline(client, raw, 0);
+		if (!polar_p) {
 			return 0;
+		}
+		POLARConfig &polar = *polar_p;
+		if (routing_out) {
+			*routing_out = (int32_t)polar.multiplexer->routing;
 		}
 		const int P = (int)polar.join_paths.size();
 		for (int p = 0; p < P; p++) {

@@ -47,6 +47,8 @@ def load():
     L.polr_host_mpx_log.argtypes = [vp, C.c_char_p, u64]
     L.polr_host_join_path_weights.argtypes = [P(C.c_double), C.c_int, C.c_double, P(C.c_double)]
     L.polr_host_generate_join_orders.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.polr_host_generate_join_orders_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp,
+                                                    vp, vp, vp]
     L.polr_host_run_pipeline.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, u64, u64, u64, vp, u64,
                                          C.c_int, vp, P(RunResult), vp, vp, vp, u64]
     L.polr_host_hash_join_probe.restype = C.c_int64
@@ -117,9 +119,11 @@ def join_path_weights(costs, regret_budget):
 
 
 def generate_join_orders(enumerator, n_probe_cols, n_build_cols, cond_left_index, est_card, max_join_orders=8,
-                         routing="adaptive_reinit"):
+                         routing="adaptive_reinit", node_info=None, return_routing=False):
     """POLARConfig::GenerateJoinOrders on join shapes.  cond_left_index: per join the list of BoundReference
-    indices of its conditions.  Returns (paths [P,k], bindings [P,k,2], dependencies [k,k]) or None."""
+    indices of its conditions.  node_info (needed by 'sample'): k + 1 tuples (base_table_card, predicate, unique) --
+    the pipeline's source, then the build side of every join.  Returns (paths [P,k], bindings [P,k,2],
+    dependencies [k,k]) or None."""
     L = load()
     k = len(n_build_cols)
     nb = np.ascontiguousarray(n_build_cols, dtype=np.int32)
@@ -128,16 +132,30 @@ def generate_join_orders(enumerator, n_probe_cols, n_build_cols, cond_left_index
     for j, c in enumerate(cond_left_index):
         li[j, :len(c)] = c
     card = np.ascontiguousarray(est_card, dtype=np.uint64)
-    paths = np.zeros((max_join_orders + 2, k), dtype=np.int32)
-    bind = np.zeros((max_join_orders + 2, k, 2), dtype=np.int32)
+    rows = max(max_join_orders, 24) + 2  # (Pipeline::Ready's BFS fallback enumerates up to 24 + 1 orders)
+    paths = np.zeros((rows, k), dtype=np.int32)
+    bind = np.zeros((rows, k, 2), dtype=np.int32)
     deps = np.zeros((k, k), dtype=np.uint8)
-    n = L.polr_host_generate_join_orders(ENUMERATOR[enumerator], capi.ROUTING[routing], k, n_probe_cols,
-                                         nb.ctypes.data, nc.ctypes.data, li.ctypes.data, card.ctypes.data,
-                                         max_join_orders, paths.ctypes.data, bind.ctypes.data, deps.ctypes.data)
+    eff = C.c_int32(capi.ROUTING[routing])
+    ncard = nflags = None
+    if node_info is not None:
+        assert len(node_info) == k + 1
+        ncard = np.ascontiguousarray([int(x[0]) for x in node_info], dtype=np.uint64)
+        nflags = np.ascontiguousarray([(1 if x[1] else 0) | (2 if x[2] else 0) for x in node_info], dtype=np.uint8)
+    n = L.polr_host_generate_join_orders_ex(ENUMERATOR[enumerator], capi.ROUTING[routing], k, n_probe_cols,
+                                            nb.ctypes.data, nc.ctypes.data, li.ctypes.data, card.ctypes.data,
+                                            max_join_orders, paths.ctypes.data, bind.ctypes.data, deps.ctypes.data,
+                                            None if ncard is None else ncard.ctypes.data,
+                                            None if nflags is None else nflags.ctypes.data, C.byref(eff))
     if n < 0:
         raise RuntimeError(L.polr_host_last_error().decode())
     if n == 0:
         return None
+    if return_routing:
+        # the routing the multiplexer ends up with: DEFAULT_PATH when only Pipeline::Ready's BFS_MIN_CARD fallback
+        # found a bank (pipeline.cpp:216-225)
+        names = {v: k_ for k_, v in capi.ROUTING.items()}
+        return paths[:n].copy(), bind[:n].copy(), deps, names[eff.value]
     return paths[:n].copy(), bind[:n].copy(), deps
 
 

@@ -359,6 +359,49 @@ QUERY_JOINS = {"q4.1": ["customer", "supplier", "part", "date"], "q4.2": ["custo
 PROBE_COLS = ["lo_custkey", "lo_suppkey", "lo_partkey", "lo_orderdate"]
 
 
+# WHERE clauses of benchmark/ssb-skew/queries/*.sql over the coded dimension attributes (strings are codes here: region
+# 1 = AMERICA, 2 = ASIA; nation 9 = UNITED STATES; p_mfgr 1..5; p_category = mfgr * 10 + 1..5)
+QUERY_WHERE = {
+    "q4.1": {"customer": "c_region = 1", "supplier": "s_region = 1", "part": "(p_mfgr = 1 OR p_mfgr = 2)"},
+    "q4.2": {"customer": "c_region = 1", "supplier": "s_region = 1", "part": "(p_mfgr = 1 OR p_mfgr = 2)",
+             "date": "(d_year = 1997 OR d_year = 1998)"},
+    "q4.3": {"customer": "c_region = 1", "supplier": "s_nation = %d" % N_UNITED_STATES, "part": "p_category = 14",
+             "date": "(d_year = 1997 OR d_year = 1998)"},
+    "q3.1": {"customer": "c_region = 2", "supplier": "s_region = 2", "date": "d_year >= 1992 AND d_year <= 1997"},
+    "q2.1": {"part": "p_category = 12", "supplier": "s_region = 1"},
+}
+DIM_KEY = {"customer": ("c_custkey", "lo_custkey"), "supplier": ("s_suppkey", "lo_suppkey"),
+           "part": ("p_partkey", "lo_partkey"), "date": ("d_datekey", "lo_orderdate")}
+
+
+def reference_form(inst, query, lineorder_cols):
+    """how the same pipeline reads for the reference: full dimension tables with their PRIMARY KEYs (load.sql:21-72)
+    and coded attribute columns, the query's filters as WHERE clauses (pushed into the build-side scans), COUNT(*) sink,
+    textual join order = QUERY_JOINS (pinned with SET disabled_optimizers TO 'join_order').  node_info: what
+    SelSampleEnumeration reads off that plan (base-table cardinality, predicate, unique) -- source first."""
+    tables = {"lineorder": dict(lineorder_cols),
+              "customer": {"c_custkey": inst.c_custkey.astype(np.uint32), "c_region": inst.c_region.astype(np.uint8),
+                           "c_nation": inst.c_nation.astype(np.uint16)},
+              "supplier": {"s_suppkey": inst.s_suppkey.astype(np.uint32), "s_region": inst.s_region.astype(np.uint8),
+                           "s_nation": inst.s_nation.astype(np.uint16)},
+              "part": {"p_partkey": inst.p_partkey.astype(np.uint32), "p_mfgr": inst.p_mfgr.astype(np.uint8),
+                       "p_category": inst.p_category.astype(np.uint8)},
+              "date": {"d_datekey": inst.d_datekey, "d_year": inst.d_year}}
+    names = QUERY_JOINS[query]
+    where = QUERY_WHERE[query]
+    sql = "SELECT COUNT(*) FROM lineorder"
+    for n in names:
+        sql += " JOIN %s ON %s = %s" % (n, DIM_KEY[n][1], DIM_KEY[n][0])
+    conds = [where[n] for n in names if n in where]
+    if conds:
+        sql += " WHERE " + " AND ".join(conds)
+    n_lo = len(next(iter(lineorder_cols.values())))
+    node_info = [(n_lo, False, False)] + [(len(tables[n][DIM_KEY[n][0]]), n in where, True) for n in names]
+    return {"tables": {k: v for k, v in tables.items() if k == "lineorder" or k in names},
+            "pk": {n: DIM_KEY[n][0] for n in names}, "query": sql,
+            "settings": ["SET disabled_optimizers TO 'join_order'"], "node_info": node_info}
+
+
 def workload(query="q4.1", sf=1.0, seed=1337, n_lo=None, n_c=None, n_s=None, n_p=None, rows=None, host_probe=True):
     """the workload dict of polr_amd.workloads for one SSB-skew query.  rows = (lo, hi): only that contiguous
     partition of lineorder (rank r of N, or the CPU baseline's sample).  host_probe=False: no probe columns are
@@ -376,7 +419,9 @@ def workload(query="q4.1", sf=1.0, seed=1337, n_lo=None, n_c=None, n_s=None, n_p
                       "payload": b["payload"], "key_src": [(-1, PROBE_COLS.index(b["probe_col"]))],
                       "perfect": (kmin, kmax) if kmax - kmin <= 1_000_000 else None, "key_range": (kmin, kmax)})
     probe = {"name": "lineorder", "rows": (lo, hi)}
+    wl = {"name": "ssb_skew_" + query.replace(".", ""), "probe": probe, "joins": joins, "instance": inst,
+          "query": query, "params": inst.params()}
     if host_probe:
         probe["cols"] = inst.lineorder(lo, hi, _NP, PROBE_COLS)
-    return {"name": "ssb_skew_" + query.replace(".", ""), "probe": probe, "joins": joins, "instance": inst,
-            "query": query, "params": inst.params()}
+        wl["ref"] = reference_form(inst, query, probe["cols"])
+    return wl

@@ -9,7 +9,9 @@
 //
 // Script language (one command per line, '#' comments):
 //   table <name> <nrows>                       start a table definition
-//   col <name> <SQLTYPE> <file>                 raw little-endian column file (i32/u32/i64/u16/...)
+//   col <name> <SQLTYPE> <file> [pk]            raw little-endian column file (i32/u32/i64/u16/...); pk: the column is the
+//                                               table's PRIMARY KEY (what benchmark/ssb-skew/init/load.sql declares for the
+//                                               dimension keys; SelSampleEnumeration reads the constraint)
 //   endtable                                    CREATE TABLE + append rows
 //   sql <statement>                             run, fail loudly on error
 //   query <tag> <statement>                     run, write rows to <outdir>/<tag>.csv, print timing
@@ -35,6 +37,7 @@ using namespace duckdb;
 
 struct ColDef {
 	std::string name, type, file;
+	bool pk = false;
 	std::vector<char> data;
 	size_t width;
 };
@@ -64,7 +67,7 @@ static void Fail(const std::string &what, const std::string &err) {
 static void LoadTable(Connection &con, const std::string &name, idx_t nrows, std::vector<ColDef> &cols) {
 	std::string ddl = "CREATE TABLE " + name + " (";
 	for (size_t i = 0; i < cols.size(); i++) {
-		ddl += (i ? ", " : "") + cols[i].name + " " + cols[i].type;
+		ddl += (i ? ", " : "") + cols[i].name + " " + cols[i].type + (cols[i].pk ? " NOT NULL PRIMARY KEY" : "");
 	}
 	ddl += ")";
 	auto r = con.Query(ddl);
@@ -166,7 +169,9 @@ int main(int argc, char **argv) {
 			tcols.clear();
 		} else if (cmd == "col") {
 			ColDef c;
-			ss >> c.name >> c.type >> c.file;
+			std::string flag;
+			ss >> c.name >> c.type >> c.file >> flag;
+			c.pk = flag == "pk";
 			tcols.push_back(c);
 		} else if (cmd == "endtable") {
 			auto t0 = std::chrono::steady_clock::now();

@@ -19,13 +19,14 @@ def available():
     return os.path.exists(DRIVER) and os.path.exists(os.path.join(_HERE, "_ref", "libduckdb_ref.so"))
 
 
-def table_lines(workdir, name, cols):
+def table_lines(workdir, name, cols, pk=None):
+    """pk: name of the column declared PRIMARY KEY (as benchmark/ssb-skew/init/load.sql does for dimension keys)"""
     n = len(next(iter(cols.values())))
     lines = ["table %s %d" % (name, n)]
     for cname, arr in cols.items():
         path = os.path.join(workdir, "%s.%s.bin" % (name, cname))
         np.ascontiguousarray(arr).tofile(path)
-        lines.append("col %s %s %s" % (cname, SQLTYPE[str(arr.dtype)], path))
+        lines.append("col %s %s %s%s" % (cname, SQLTYPE[str(arr.dtype)], path, " pk" if cname == pk else ""))
     lines.append("endtable")
     return lines
 
