@@ -1,25 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- probe-tuples/s of the POLAR multiplexed hash-join pipeline on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload job_light_01] [--routing adaptive_reinit]
+  python bench.py --gpus N --steps K --warmup W [--workload ssb_skew_q41 --scale 100] [--routing adaptive_reinit]
 
-One *step* = one complete pass of the hot path over the workload's probe side: a fresh multiplexer
-routes every source chunk (device-resident router), the path kernel probes the routed slices through
-the bank of join orders and feeds the per-join counters back into the reward -- inputs (probe columns,
-selection, build tables) already resident in HBM when the clock starts.  The sink is COUNT(*) (only
-counters leave the device), as in JOB-light.  Default workload = BASELINE.json configs[1]
-("JOB-light 3-way join on 1 MI355X, single POLR pipeline, build sides in HBM") at the IMDB
-cardinalities, synthetic data of that shape (no dataset access offline).
+One *step* = one complete pass of the hot path over the workload's probe side: fresh multiplexers route every source
+chunk (device-resident routers), the pool of probe waves sends the routed slices through the bank of join orders and
+feeds the per-join counters back into the reward -- inputs (probe columns, selection, build tables) already resident
+in HBM when the clock starts.  The sink is COUNT(*) (only counters leave the device).
 
-Multi-GPU (torchrun, one rank per GPU): the path shards by probe partition -- every rank owns a
-same-sized partition of the probe side (weak scaling) and its own multiplexer, exactly like one
-PipelineExecutor per thread in the reference; the build sides are built on rank 0 and broadcast
-once over RCCL before the clock starts; no collective on the data path.
+Default workload = BASELINE.json configs[2], the configuration the metric's roofline is quoted on: SSB-skew Q4.1 at
+SF100 -- lineorder 600 M rows x {customer, supplier, part, date}, the skew of benchmark/ssb-skew/init/load.sql:80-253
+applied exactly (polr_amd/ssb_skew.py), generated on the device; join orders from the reference's default enumerator
+(`sample`, max_join_orders = 3).  At N = 1 the same JSON line carries `sub_records` for the JOB 18a shape (the query
+the >= 10x target is quoted on) and the JOB-light 01 shape (configs[1]).
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel =
-polr_path_kernel, algorithmic bytes per SURVEY.md 8(d) over HIP-event kernel time) and
-`cpu_baseline` (the reference itself, compiled from its sources by oracle/ref_build.mk, timed on
-this box's host cores; falls back to the oracle port when the reference build is absent).
+Multi-GPU (torchrun, one rank per GPU): the path shards by probe partition -- rank r owns the r-th contiguous
+lo_orderkey range of a lineorder N times as long (weak scaling; `--strong`: the N-th part of the same table) and its own
+multiplexers, exactly like one PipelineExecutor per thread in the reference; the build sides are built on rank 0 and
+broadcast once over RCCL before the clock starts; no collective on the data path.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the pool kernel, algorithmic
+bytes per SURVEY.md 8(d) over HIP-event kernel time) and `cpu_baseline` (the reference itself, compiled from its
+sources by oracle/ref_build.mk, timed on this box's host cores on a stated contiguous sample).
 """
 import argparse
 import json
@@ -34,6 +36,8 @@ sys.path.insert(0, os.path.join(ROOT, "duckdb-polr_amd", "python"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+SSB_QUERIES = {"ssb_skew_q41": "q4.1", "ssb_skew_q42": "q4.2", "ssb_skew_q43": "q4.3", "ssb_skew_q31": "q3.1",
+               "ssb_skew_q21": "q2.1"}
 
 
 class _DevBuf:
@@ -53,7 +57,7 @@ def ref_capacity(n):
     return p
 
 
-def algorithmic_bytes(wl, joins_info, paths, tuples_per_path, stage_out):
+def algorithmic_bytes(joins_info, paths, tuples_per_path, stage_out):
     """per input tuple of join j:  chained  K + 8 + c(1+K+8) + m(P+4+P),
     perfect  K + 1 + m(4+4);  c = m + n_build/capacity (matching rows + expected bucket collisions at
     the reference's load factor), m = stage outputs / stage inputs, P = payload bytes gathered (0: the
@@ -74,19 +78,6 @@ def algorithmic_bytes(wl, joins_info, paths, tuples_per_path, stage_out):
     return total
 
 
-def build_workload(name, scale, seed):
-    from polr_amd import workloads
-    if name == "job_light_01":
-        return workloads.job_light_01(scale=scale, seed=seed)
-    if name == "job_q18":
-        return workloads.job_q18(scale=scale, seed=seed)
-    if name == "ssb_skew_q41":
-        return workloads.ssb_skew_q41(sf=scale, seed=seed)
-    if name == "star_skew":
-        return workloads.star_skew(n_fact=int(2_000_000 * scale), seed=seed)
-    raise SystemExit("unknown workload %s" % name)
-
-
 def chunk_offsets_for(sel, n_rows, V):
     """source chunk boundaries in selection order: the scan emits one (thinned) chunk per V-row
     vector, never an empty one"""
@@ -97,161 +88,181 @@ def chunk_offsets_for(sel, n_rows, V):
     return bounds[keep]
 
 
-def cpu_baseline(wl, routing, n_tuples, args):
-    """rank 0, N=1 only.  The reference's own CPU POLAR path on the same tables and the same pinned
-    pipeline (same routing strategy), timed by its own PRAGMA enable_measure_pipeline."""
+def reference_runs(tables, pk, query, settings, n_tuples, repeat=5):
+    """the reference's POLAR pipeline on `tables` at 1 thread and at all host cores: {threads: (median ms, count)}"""
     from oracle import ref_run
     nproc = os.cpu_count() or 1
-    if ref_run.available() and "ref" in wl:
-        ref = wl["ref"]
+    out = {}
+    for threads in sorted(set([1, nproc])):
+        ms, wall, result = ref_run.time_polar_pipeline(tables, query, settings, threads, repeat=repeat, pk=pk)
+        count = None
+        try:
+            count = int(result.strip().splitlines()[1].split(",")[0])
+        except Exception:
+            pass
+        out[threads] = (float(np.median(ms)) if ms else None, count)
+    return out
+
+
+def pick_baseline(runs, n_tuples):
+    """best thread count among the runs whose COUNT(*) equals the single-threaded answer (the reference's POLAR pipeline
+    has been seen to lose rows with many threads; such a run is reported, never used as the baseline)"""
+    detail = {}
+    ref_count = runs.get(1, (None, None))[1]
+    best = None
+    for threads, (ms, count) in sorted(runs.items()):
+        detail["threads_%d_pipeline_ms" % threads] = None if ms is None else round(ms, 3)
+        detail["count_star_threads_%d" % threads] = count
+        if ms is None or count != ref_count:
+            continue
+        v = n_tuples / (ms / 1e3)
+        if best is None or v > best[0]:
+            best = (v, threads)
+    return best, detail
+
+
+def cpu_baseline_generic(wl, routing, n_tuples, enumerator):
+    """JOB-shaped workloads: the reference on the whole workload (a few tens of ms per run)"""
+    from oracle import ref_run
+    if not (ref_run.available() and "ref" in wl):
+        return None
+    ref = wl["ref"]
+    settings = list(ref["settings"]) + ["SET multiplexer_routing TO '%s'" % routing,
+                                        "SET join_enumerator TO '%s'" % enumerator]
+    runs = reference_runs(ref["tables"], ref.get("pk", {}), ref["query"], settings, n_tuples)
+    best, detail = pick_baseline(runs, n_tuples)
+    if not best:
+        return None
+    return {"value": best[0], "unit": "probe-tuples/s", "cores": best[1], "kind": "reference",
+            "sample": "whole workload, median of 5 runs of the reference's POLAR pipeline (Pipeline::Schedule->Finalize "
+                      "incl. table scan + pushed-down filter + count sink), threads in {1,%d}; only runs whose COUNT(*) "
+                      "equals the single-threaded answer are candidates" % (os.cpu_count() or 1), **detail}
+
+
+def cpu_baseline_ssb(inst, query, routing, args, sample_rows):
+    """SSB-skew: the reference on two CONTIGUOUS samples of lineorder, one from each skew phase (rows just below and
+    just above the lo_orderkey 400 M mark would mix the phases; the samples start at 1/3 and at 5/6 of the table), full
+    dimension tables with their PRIMARY KEYs, the same query, `sample` enumerator, same max_join_orders.  The table is
+    2/3 phase one and 1/3 phase two: probe-tuples/s = 1 / (2/3 t1 + 1/3 t2) with t_i the measured seconds per tuple."""
+    from oracle import ref_run
+    from polr_amd import ssb_skew
+    if not ref_run.available():
+        return None
+    n = (min(sample_rows, inst.n_lo // 8) // 1024) * 1024  # whole source chunks
+    starts = [inst.n_lo // 3 - n // 2, (inst.n_lo * 5) // 6 - n // 2]
+    starts = [max(0, (s // 1024) * 1024) for s in starts]
+    per_thread = {}
+    detail = {"sample_rows_each": n, "sample_starts": starts}
+    counts = []
+    for ph, s0 in enumerate(starts):
+        cols = inst.lineorder(s0, s0 + n)
+        ref = ssb_skew.reference_form(inst, query, cols)
         settings = list(ref["settings"]) + ["SET multiplexer_routing TO '%s'" % routing,
-                                            "SET join_enumerator TO 'each_last_once'"]
-        best = None
-        detail = {}
-        for threads in sorted(set([1, nproc])):
-            ms, wall, result = ref_run.time_polar_pipeline(ref["tables"], ref["query"], settings, threads, repeat=5)
-            try:  # the reference's answer (COUNT(*)): checked against the device's count at full size
-                detail["count_star_threads_%d" % threads] = int(result.strip().splitlines()[1].split(",")[0])
-            except Exception:
-                pass
-            if not ms:
-                continue
-            med = float(np.median(ms))
-            detail["threads_%d_pipeline_ms" % threads] = round(med, 3)
-            v = n_tuples / (med / 1e3)
+                                            "SET join_enumerator TO '%s'" % args.enumerator_name,
+                                            "SET max_join_orders TO %d" % args.max_join_orders]
+        runs = reference_runs(ref["tables"], ref["pk"], ref["query"], settings, n, repeat=3)
+        ref_count = runs.get(1, (None, None))[1]
+        counts.append(ref_count)
+        for threads, (ms, count) in runs.items():
+            detail["phase%d_threads_%d_pipeline_ms" % (ph + 1, threads)] = None if ms is None else round(ms, 3)
+            detail["phase%d_count_star_threads_%d" % (ph + 1, threads)] = count
+            if ms is not None and count == ref_count:
+                per_thread.setdefault(threads, {})[ph] = ms / 1e3 / n
+    best = None
+    for threads, t in per_thread.items():
+        if len(t) == 2:
+            v = 1.0 / (2.0 / 3.0 * t[0] + 1.0 / 3.0 * t[1])
             if best is None or v > best[0]:
                 best = (v, threads)
-        if best:
-            return {"value": best[0], "unit": "probe-tuples/s", "cores": best[1], "kind": "reference",
-                    "sample": "whole workload, median of 5 runs of the reference's POLAR pipeline "
-                              "(Pipeline::Schedule->Finalize incl. scan+filter+count sink), threads in {1,%d}" % nproc,
-                    **detail}
-    # port: the oracle restatement, single thread, on a bounded prefix of the probe side
-    from oracle import polr_oracle as orc
-    from polr_amd import workloads
-    k = len(wl["joins"])
-    ojoins = []
-    for j in wl["joins"]:
-        ht = orc.HashTable(j["keys"], list(j["payload"].values()))
-        if j.get("perfect") is not None:
-            ht.make_perfect(*j["perfect"])
-        ojoins.append(orc.JoinSpec(ht, j["key_src"]))
-    sel = wl["probe"].get("filter_sel")
-    sample = min(n_tuples, 4_000_000)
-    cols = list(wl["probe"]["cols"].values())
-    if sel is not None:
-        sel = sel[:sample]
-    else:
-        cols = [c[:sample] for c in cols]
-    t0 = time.time()
-    orc.run_pipeline(cols, ojoins, workloads.default_paths(k), routing=routing, collect_output=False, sel=sel)
-    dt = time.time() - t0
-    return {"value": sample / dt, "unit": "probe-tuples/s", "cores": 1, "kind": "port",
-            "sample": "first %d probe tuples through the oracle restatement (single thread)" % sample}
+    if not best:
+        return None
+    return {"value": best[0], "unit": "probe-tuples/s", "cores": best[1], "kind": "reference",
+            "sample": "two contiguous samples of %d lineorder rows (rows %d.. of phase one, %d.. of phase two), full "
+                      "dimension tables; median of 3 runs of the reference's POLAR pipeline each (Pipeline::Schedule->"
+                      "Finalize incl. table scan + count sink), threads in {1,%d}; value = 1 / (2/3 t1 + 1/3 t2), the "
+                      "phases' shares of the table; only runs whose COUNT(*) equals the single-threaded answer count"
+                      % (n, starts[0], starts[1], os.cpu_count() or 1),
+            "sample_count_star": counts, **detail}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="job_light_01")
-    ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--routing", default="adaptive_reinit")
-    ap.add_argument("--regret-budget", type=float, default=0.01)
-    ap.add_argument("--init-tuple-count", type=int, default=1024)
-    ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
-    ap.add_argument("--max-join-orders", type=int, default=8, help="SET max_join_orders (bank size cap)")
-    ap.add_argument("--executors", type=int, default=0,
-                    help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
-                         "contiguous share of the source chunks -- the counterpart of the reference's worker "
-                         "threads (one PipelineExecutor + MultiplexerState per thread, pipeline.cpp:145-174). "
-                         "0 (default) = 8, one executor per XCD of the MI355X, and 64 for partitions of more than 65 536 "
-                         "chunks (table-sized adaptive runs hide their exploration rounds behind each other); 1 = "
-                         "the single-executor trace the parity tests pin against the single-threaded reference")
-    ap.add_argument("--launch", default="resident", choices=["resident", "rounds"],
-                    help="resident: the whole pass is ONE launch (device-resident routing loop, "
-                         "polr_mpx_run_resident); rounds: one self-routing launch per routing round "
-                         "(polr_mpx_run / _run_many)")
-    ap.add_argument("--reference-tables", action="store_true",
-                    help="index the build sides exactly as the reference's planner would (perfect table only below its "
-                         "1 M-value cap); default: polr_ht_finalize_auto -- dense unique integer keys of any range "
-                         "become 1-bit-per-value perfect tables that stay in L2")
-    ap.add_argument("--host-filter", action="store_true",
-                    help="upload the host-computed selection instead of running the pushed-down filter of the source "
-                         "scan on the device (polr_pipeline_scan_filter); either way it happens before the clock starts")
-    ap.add_argument("--morsels", type=int, default=0,
-                    help="M > 0: the executors share all source chunks and pull them M chunks at a time from one "
-                         "device-side cursor (morsel-driven, like the reference's worker threads; 120 = a row group) "
-                         "instead of each owning a fixed contiguous range")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="P > 1: P passes in flight -- P sets of executors on P streams, each sized for 1/P of the "
-                         "device (POLR_RUN_SHARE), passes enqueued round-robin; the exploration rounds of one pass "
-                         "overlap the table-sized round of another (inter-query parallelism; per-pass latency rises)")
-    ap.add_argument("--sync-every-step", action="store_true",
-                    help="read the statistics of every pass back before enqueueing the next one (default: the K "
-                         "passes of the timed region are enqueued back to back on the stream, one synchronisation at "
-                         "the end -- every pass still resets, routes, probes and closes itself on the device)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true")
-    args = ap.parse_args()
+class Case:
+    """one measured workload: tables, join orders, pipeline, executors"""
+    pass
 
-    # executors run on separate HIP streams; let the runtime map them to separate hardware queues
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm.  POLR_DIST_BACKEND=gloo + POLR_SHARE_DEVICE=1 rehearse the N > 1 path on a
-        # one-GPU box (all ranks on cuda:0; RCCL refuses two ranks on one device)
-        backend = os.environ.get("POLR_DIST_BACKEND", "nccl")
-        if os.environ.get("POLR_SHARE_DEVICE"):
-            local_rank = 0
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from polr_amd import capi, workloads
+def run_case(name, scale, args, env, steps, warmup, with_cpu):
+    """measure one workload; returns the record (dict).  env: torch, dist, dev, ctx, world, rank"""
+    torch, dist, dev, ctx, world, rank = env["torch"], env["dist"], env["dev"], env["ctx"], env["world"], env["rank"]
+    from polr_amd import capi, workloads, ssb_skew
     from polr_amd import dist as pdist
-    ctx = capi.Context(local_rank)  # raises without the HIP library / a gfx950 device: no fallback
+    from polr_amd import host as phost
     V = args.chunk_size
-
-    # ---- workload: same build sides everywhere, one probe partition per rank (weak scaling) -------
-    wl0 = build_workload(args.workload, args.scale, workloads.SEED)
-    wl = wl0 if rank == 0 else build_workload(args.workload, args.scale,
-                                              pdist.probe_partition_seed(workloads.SEED, rank))
-    k = len(wl0["joins"])
-    if "cond_left_index" in wl0:
-        # joins keyed by build columns of earlier joins: the join orders come from the host mirror of
-        # POLARConfig::GenerateJoinOrders (dependencies respected), as they would inside the engine
-        from polr_amd import host as phost
-        gen = phost.generate_join_orders("each_last_once", len(wl0["probe"]["cols"]),
-                                         [len(j["payload"]) for j in wl0["joins"]], wl0["cond_left_index"],
-                                         [len(j["keys"][0]) for j in wl0["joins"]],
-                                         max_join_orders=max(1, args.max_join_orders), routing=args.routing)
-        if gen is None:
-            raise SystemExit("POLAR does not apply to this pipeline")
-        paths = gen[0]
+    is_ssb = name in SSB_QUERIES
+    enumerator = args.enumerator if args.enumerator != "auto" else ("sample" if is_ssb else "each_last_once")
+    args.enumerator_name = enumerator
+    t_gen0 = time.time()
+    inst = None
+    if is_ssb:
+        query = SSB_QUERIES[name]
+        z = ssb_skew.sizes(scale)
+        n_total = z["n_lo"] * (1 if args.strong else world)
+        wl0 = ssb_skew.workload(query, sf=scale, n_lo=n_total, host_probe=False)
+        inst = wl0["instance"]
+        lo, hi = (rank * n_total) // world, ((rank + 1) * n_total) // world
+        lo, hi = (lo // V) * V, ((hi // V) * V if rank + 1 < world else hi)
+        names = list(ssb_skew.PROBE_COLS)
+        cols_t = inst.lineorder_torch(lo, hi, dev, cols=names)
+        tens = [cols_t[c] for c in names]
+        signed = [False] * len(names)
+        n_rows = hi - lo
+        sel = None
+        flt = None
+        dim_rows = {"customer": len(inst.c_custkey), "supplier": inst.n_s, "part": inst.n_p, "date": 2556}
+        # what SelSampleEnumeration reads off the plan: base-table cardinality, pushed-down predicate, PRIMARY KEY
+        node_info = [(n_total, False, False)] + [(dim_rows[j["name"]], j["name"] in ssb_skew.QUERY_WHERE[query], True)
+                                                 for j in wl0["joins"]]
+        cond_left = [[j["key_src"][0][1]] for j in wl0["joins"]]
+        n_build_cols = [0] * len(wl0["joins"])
+        est = [len(j["keys"][0]) for j in wl0["joins"]]
     else:
-        paths = workloads.default_paths(k, "each_last_once")[:max(1, args.max_join_orders)]
+        builder = {"job_light_01": workloads.job_light_01, "job_q18": workloads.job_q18}.get(name)
+        if builder is None:
+            raise SystemExit("unknown workload %s" % name)
+        wl0 = builder(scale=scale, seed=workloads.SEED)
+        wl = wl0 if rank == 0 else builder(scale=scale, seed=pdist.probe_partition_seed(workloads.SEED, rank))
+        probe = wl["probe"]
+        names = list(probe["cols"].keys())
+        n_rows = len(probe["cols"][names[0]])
+        tens = [torch.from_numpy(np.ascontiguousarray(probe["cols"][n])).to(dev) for n in names]
+        signed = [probe["cols"][n].dtype.kind == "i" for n in names]
+        sel = probe.get("filter_sel")
+        flt = probe.get("filter")
+        node_info = None
+        cond_left = wl0.get("cond_left_index") or [[j["key_src"][0][1]] for j in wl0["joins"]]
+        n_build_cols = [len(j["payload"]) for j in wl0["joins"]]
+        est = [len(j["keys"][0]) for j in wl0["joins"]]
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen0
+    k = len(wl0["joins"])
 
-    # build sides: rank 0 builds in HBM, everyone else receives them over RCCL (one broadcast per buffer)
-    joins = []
-    joins_info = []
-    for j in wl0["joins"]:
-        joins_info.append({"key_bytes": sum(a.dtype.itemsize for a in j["keys"]), "n_rows": len(j["keys"][0]),
-                           "perfect": False})
+    # ---- the bank of join orders: the host mirror of POLARConfig::GenerateJoinOrders with the session's enumerator
+    gen = phost.generate_join_orders(enumerator, len(names), n_build_cols, cond_left, est,
+                                     max_join_orders=max(1, args.max_join_orders), routing=args.routing,
+                                     node_info=node_info, return_routing=True)
+    if gen is None:
+        raise SystemExit("POLAR does not apply to this pipeline (fewer than two join orders)")
+    paths, routing = gen[0], gen[3]
+    if args.pin_path is not None:
+        # measurement aid: put join order P of the bank first, so that `--routing default_path` runs the whole table
+        # down that one order (the kernel's rate on it, without routing)
+        order = [args.pin_path] + [i for i in range(len(paths)) if i != args.pin_path]
+        paths = paths[order]
+
+    # ---- build sides: rank 0 builds in HBM, everyone else receives them over RCCL (one broadcast per buffer)
+    joins_info = [{"key_bytes": sum(a.dtype.itemsize for a in j["keys"]), "n_rows": len(j["keys"][0]), "perfect": False}
+                  for j in wl0["joins"]]
     t_build0 = time.time()
+    joins = []
     if rank == 0:
         joins = capi.build_joins(ctx, wl0, auto=not args.reference_tables)
     bcast_bytes = 0
@@ -279,30 +290,23 @@ def main():
     for x in range(k):
         joins_info[x]["perfect"] = joins[x][0].info()["kind"] == 1
 
-    # probe side resident in HBM as torch tensors (plumbing only)
-    probe = wl["probe"]
-    names = list(probe["cols"].keys())
-    n_rows = len(probe["cols"][names[0]])
-    tens = [torch.from_numpy(np.ascontiguousarray(probe["cols"][n])).to(dev) for n in names]
-    cols = [capi.dev_col(t.data_ptr(), t.element_size(), signed=probe["cols"][n].dtype.kind == "i")
-            for t, n in zip(tens, names)]
+    cols = [capi.dev_col(t.data_ptr(), t.element_size(), signed=s) for t, s in zip(tens, signed)]
     pipe = capi.Pipeline(ctx, cols, n_rows, joins, paths)
-    sel = probe.get("filter_sel")
-    sel_t = None
     scan_info = None
-    device_scan = bool(probe.get("filter")) and not args.host_filter
+    device_scan = bool(flt) and not args.host_filter
+    sel_t = None
     if device_scan:
         # source side on the device: the pushed-down filter of the table scan thins the
         # 1024-row vectors into the chunks the multiplexer sees; selection and chunk boundaries stay in HBM
-        flt = [(names.index(c), op, const) for c, op, const in probe["filter"]]
+        f3 = [(names.index(c), op, const) for c, op, const in flt]
         best = None
         for _ in range(5):
             torch.cuda.synchronize()
             t_s = time.perf_counter()
-            n_tuples, n_chunks = pipe.scan_filter(flt, vector_size=V)
+            n_tuples, n_chunks = pipe.scan_filter(f3, vector_size=V)
             dt_s = time.perf_counter() - t_s
             best = dt_s if best is None else min(best, dt_s)
-        scan_bytes = 2 * sum(probe["cols"][c].dtype.itemsize for c, _, _ in probe["filter"]) * n_rows + 4 * n_tuples
+        scan_bytes = 2 * sum(tens[names.index(c)].element_size() for c, _, _ in flt) * n_rows + 4 * n_tuples
         scan_info = {"rows": n_rows, "selected": int(n_tuples), "chunks": int(n_chunks),
                      "ms": round(best * 1e3, 4), "algorithmic_bytes": int(scan_bytes),
                      "GB/s": round(scan_bytes / best / 1e9, 1),
@@ -315,63 +319,50 @@ def main():
             sel_t = torch.from_numpy(np.ascontiguousarray(sel)).to(dev)
             pipe.set_selection(sel_t.data_ptr(), device=True, n=len(sel))
         n_tuples = len(sel) if sel is not None else n_rows
-    budget = args.regret_budget
-    if args.routing == "exponential_backoff":
-        budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
-    if not device_scan:
         offs = chunk_offsets_for(sel, n_rows, V)
         n_chunks = len(offs) - 1 if offs is not None else (n_tuples + V - 1) // V
-    want_e = args.executors if args.executors > 0 else (64 if n_chunks > 65536 else 8)
+    budget = args.regret_budget
+    if routing == "exponential_backoff":
+        budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
+    want_e = args.executors if args.executors > 0 else (128 if n_chunks > 65536 else 32)
     E = max(1, min(want_e, n_chunks))
-    P = max(1, args.streams) if args.launch == "resident" and not args.sync_every_step else 1
+    P = max(1, args.streams) if not args.sync_every_step else 1
     sets = []
     for _p in range(P):
         execs = []
         for e in range(E):
-            m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=budget,
-                                       init_tuple_count=args.init_tuple_count, log_rounds=False)
+            m = capi.DeviceMultiplexer(pipe, routing, chunk_size=V, regret_budget=budget,
+                                       init_tuple_count=args.init_tuple_count, atc_multiplier=args.atc_multiplier,
+                                       log_rounds=False)
             if device_scan:
                 m.use_scan_chunks()
             elif offs is not None:
                 m.set_chunk_offsets(offs)
-            execs.append((m, None, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
+            execs.append((m, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
         sets.append(execs)
-    execs = sets[0]
     results = [None] * E
-    mpxs = [x[0] for x in execs]
-    ranges = [(x[2], x[3]) for x in execs]
+    ranges = [(x[1], x[2]) for x in sets[0]]
     all_mpxs = [x[0] for ex in sets for x in ex]
     step_no = [0]
-
-    pipelined = args.launch == "resident" and not args.sync_every_step
+    pipelined = not args.sync_every_step
 
     def step(fetch=True):
-        if args.launch == "resident":
-            # fresh multiplexer states, the whole pass and the closing FinalizePathRun: one launch
-            cur = [x[0] for x in sets[step_no[0] % P]]
-            step_no[0] += 1
-            if args.morsels > 0:
-                capi.run_resident_morsels(cur, 0, n_chunks, args.morsels, reset=True, finish=True, share=P)
-            else:
-                capi.run_resident(cur, ranges, reset=True, finish=True, share=P)
-            if fetch:
-                for ex in sets:  # (settles every stream; the statistics reported are the last pass's)
-                    got = capi.finish_many([x[0] for x in ex])
-                    if ex[0][0] is cur[0]:
-                        results[:] = got
-            return results
-        for m in mpxs:
-            m.reset()
-        if E == 1:
-            mpxs[0].run(*ranges[0])
+        # fresh multiplexer states, the whole pass and the closing FinalizePathRun: one launch
+        cur = [x[0] for x in sets[step_no[0] % P]]
+        step_no[0] += 1
+        if args.morsels > 0:
+            capi.run_resident_morsels(cur, 0, n_chunks, args.morsels, reset=True, finish=True, share=P)
         else:
-            capi.run_many(mpxs, ranges)  # one host thread pumps all executors; rounds overlap on the device
-        results[:] = capi.finish_many(mpxs)
+            capi.run_resident(cur, ranges, reset=True, finish=True, share=P)
+        if fetch:
+            for ex in sets:  # (settles every stream; the statistics reported are the last pass's)
+                got = capi.finish_many([x[0] for x in ex])
+                if ex[0][0] is cur[0]:
+                    results[:] = got
         return results
 
     def merged(res):
-        out = {"num_intermediates": 0, "num_rounds": 0,
-               "input_tuple_count_per_path": [0] * len(paths),
+        out = {"num_intermediates": 0, "num_rounds": 0, "input_tuple_count_per_path": [0] * len(paths),
                "stage_out": [[0] * k for _ in range(len(paths))]}
         for r in res:
             out["num_intermediates"] += r["num_intermediates"]
@@ -382,23 +373,22 @@ def main():
                     out["stage_out"][p][j] += r["stage_out"][p][j]
         return out
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     # ---- timed region: K steps, barrier + synchronize on both sides, no profiling hooks -----------
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(fetch=not pipelined or i == args.steps - 1)
+    for i in range(steps):
+        step(fetch=not pipelined or i == steps - 1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0  # this rank's K steps; the job's time is the MAX over ranks (below)
     if world > 1:
         dist.barrier()
     st = merged(results)
-    # ---- same K steps again with a HIP event pair around every path-kernel launch (on the launch
-    # stream) to get the dominant kernel's device time for the roofline; the event records cost ~8 us of
-    # host time per launch, which is why they are kept out of the region `value` is computed from
+    # ---- same K steps again with a HIP event pair around every pool-kernel launch (on the launch stream) to get the
+    # dominant kernel's device time for the roofline; kept out of the region `value` is computed from
     kernel_ms, launches, dt_events = 0.0, 0, None
     if not args.no_kernel_events:
         for m in all_mpxs:
@@ -406,8 +396,8 @@ def main():
             m.enable_timing(True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(fetch=not pipelined or i == args.steps - 1)
+        for i in range(steps):
+            step(fetch=not pipelined or i == steps - 1)
         torch.cuda.synchronize()
         dt_events = time.perf_counter() - t1
         for m in all_mpxs:
@@ -416,58 +406,60 @@ def main():
             launches += n_e
             m.enable_timing(False)
 
-    value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, n_tuples, dt, args.steps)
-
+    value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, n_tuples, dt, steps)
+    rec = None
     if rank == 0:
-        alg = algorithmic_bytes(wl, joins_info, paths.tolist(), st["input_tuple_count_per_path"], st["stage_out"])
+        alg = algorithmic_bytes(joins_info, paths.tolist(), st["input_tuple_count_per_path"], st["stage_out"])
+        info = pipe.launch_info(False)
         roof = None
         if launches:
-            sec = kernel_ms / 1e3 / args.steps  # path-kernel time of one step (all its routing rounds)
+            sec = kernel_ms / 1e3 / steps
             achieved = alg / sec / 1e9
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-            if os.path.exists(tp):
-                try:
-                    tj = json.load(open(tp))
-                    # measured PMC traffic of the SAME kernel and configuration only (else: not measured)
-                    same = tj.get("kernel") == ("polr_resident_kernel" if args.launch == "resident" else
-                                                "polr_path_kernel") and \
-                        tj.get("config", {}).get("executors_per_gpu") == E and \
-                        tj.get("config", {}).get("routing") == args.routing and args.scale == 1.0
-                    traffic = tj.get("hbm_bytes_per_launch") if same else None
-                except Exception:
-                    traffic = None
+            working_set = sum(t.numel() * t.element_size() for t in tens) + \
+                sum(int(j[0].info()["device_bytes"]) for j in joins)
             roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "polr_resident_kernel" if args.launch == "resident" else "polr_path_kernel",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None,
+                    "traffic_note": "not measured inside bench.py (PMC passes are separate rocprofv3 runs: profiles/)",
+                    "kernel": "polr_pool_flat_kernel" if info.get("flat") else "polr_pool_kernel",
                     "algorithmic_bytes_per_step": round(alg),
-                    "kernel_ms_per_step": round(kernel_ms / args.steps, 4),
-                    "launches_per_step": launches / args.steps,
-                    "ms_per_step_with_events": round(dt_events / args.steps * 1e3, 4),
-                    "note": ("one launch = the whole pass: every executor's routing loop and all its probe rounds "
-                             "(the kernel time includes the device-side waits between dependent routing rounds)"
-                             if args.launch == "resident" else
-                             "one launch = one routed path run (probe + route next); algorithmic bytes and kernel "
-                             "time are summed over all launches of a step")}
+                    "algorithmic_bytes_per_tuple": round(alg / max(n_tuples, 1), 3),
+                    "kernel_ms_per_step": round(kernel_ms / steps, 4),
+                    "launches_per_step": launches / steps,
+                    "ms_per_step_with_events": round(dt_events / steps * 1e3, 4),
+                    "working_set_bytes": int(working_set),
+                    "note": "one launch = the whole pass: every executor's routing loop and all probe rounds (the kernel "
+                            "time includes the device-side waits between dependent routing rounds)"}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if with_cpu:
             try:
-                cpu = cpu_baseline(wl0, args.routing, n_tuples, args)
-                cpu["value"] = round(cpu["value"], 1)
+                if is_ssb:
+                    cpu = cpu_baseline_ssb(inst, SSB_QUERIES[name], routing, args, args.cpu_sample_rows)
+                else:
+                    cpu = cpu_baseline_generic(wl0, routing, n_tuples, enumerator)
+                if cpu:
+                    cpu["value"] = round(cpu["value"], 1)
             except Exception as e:  # the baseline must never take the measurement down
-                cpu = {"value": None, "error": str(e)[:200]}
-        line = {
+                cpu = {"value": None, "error": str(e)[:300]}
+        if is_ssb:
+            desc = ("%s: SSB-skew %s at SF%g -- lineorder %d rows per GPU (rows %d..%d of %d, contiguous lo_orderkey "
+                    "range) x %s; skew = benchmark/ssb-skew/init/load.sql:80-253 applied to synthetic SSB base tables, "
+                    "generated on the device" % (name, SSB_QUERIES[name], scale, n_rows, lo, hi, n_total,
+                                                 " x ".join("%s %d" % (j["name"], len(j["keys"][0])) for j in wl0["joins"])))
+        else:
+            desc = "%s (IMDB cardinalities x%.3g: %d probe tuples after the pushed-down filter; builds %s)" % (
+                name, scale, n_tuples, ", ".join("%s %d" % (j["name"], len(j["keys"][0])) for j in wl0["joins"]))
+        rec = {
             "metric": "probe-tuples/s", "value": round(value, 1), "unit": "tuples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "dtype_note": "32-bit keys hashed and compared in 64-bit integer arithmetic; f64 only in the reward",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt_max / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64",
+            "dtype_note": "32-bit keys; hash / range arithmetic in 32/64-bit integers; f64 only in the reward",
             "data": "synthetic",
-            "config": {"workload": "%s (JOB-light 01 shape, IMDB cardinalities x%.3g: %d probe tuples after the "
-                                   "company_type_id filter, builds title %d + movie_info_idx %d rows)" %
-                                   (args.workload, args.scale, n_tuples, joins_info[0]["n_rows"],
-                                    joins_info[1]["n_rows"]) if args.workload == "job_light_01" else args.workload,
-                       "routing": args.routing, "join_orders": int(len(paths)), "chunk_size": V,
+            "config": {"workload": desc, "routing": routing, "join_enumerator": enumerator,
+                       "max_join_orders": args.max_join_orders, "join_orders": paths.tolist(), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
-                       "sink": "count(*)", "probe_partition_per_gpu": n_tuples, "executors_per_gpu": E, "launch": args.launch,
+                       "sink": "count(*)", "probe_partition_per_gpu": int(n_tuples), "executors_per_gpu": E,
+                       "launch": "pool (one launch per pass: %d router waves + shared probe waves)" % E,
                        "chunks_per_executor": ("morsels of %d" % args.morsels) if args.morsels > 0 else "fixed ranges",
                        "build_tables": ["perfect" if ji["perfect"] else "hash" for ji in joins_info],
                        "passes_in_flight": ("%d streams, 1/%d of the device each" % (P, P)) if P > 1 else
@@ -475,29 +467,141 @@ def main():
             "total_intermediates": int(st["num_intermediates"]),
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],
-            "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
-            "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch_info": pipe.launch_info(False),
+            "generate_s": round(t_gen, 3), "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
+            "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch_info": info,
+            "timed_region": {"gpu": "routing + probing of every source chunk; probe key columns read from HBM inside the "
+                                    "pass" + ("; the pushed-down filter (scan_filter.ms) runs before the clock starts"
+                                              if scan_info else "; the query has no probe-side filter"),
+                             "cpu": "the reference's whole POLAR pipeline: table scan (+ pushed-down filter) + joins + "
+                                    "count sink"},
         }
-        # COUNT(*) of the pass = output tuples of the last join over all join orders; next to the reference's answer
-        line["count_star"] = int(sum(st["stage_out"][p][k - 1] for p in range(len(paths))))
-        if cpu and cpu.get("count_star_threads_1") is not None:
-            # the single-threaded reference is the parity anchor (as in the golden fixtures).  With many worker
-            # threads the reference's POLAR pipeline has been seen to return a smaller COUNT(*) on this workload
-            # (256 threads: 37 397 instead of 37 439; 1 and 8 threads agree with the device) -- reported, not hidden.
-            line["count_star_matches_reference"] = bool(cpu["count_star_threads_1"] == line["count_star"])
-            mt = [v for kk, v in cpu.items() if kk.startswith("count_star_threads_") and kk != "count_star_threads_1"]
-            if mt and any(v != cpu["count_star_threads_1"] for v in mt):
-                line["reference_multithreaded_count_differs"] = True
+        if is_ssb:
+            rec["config"]["ssb_skew_params"] = {k_: v for k_, v in wl0["params"].items() if k_ != "year_band_ends"}
+        rec["count_star"] = int(sum(st["stage_out"][p][k - 1] for p in range(len(paths))))
+        if scan_info:
+            e2e_ms = dt_max / steps * 1e3 + scan_info["ms"]
+            rec["value_with_scan"] = round(total_tuples / (e2e_ms / 1e3), 1)
         if cpu and cpu.get("value"):
-            line["gpu_over_cpu"] = round(value / cpu["value"], 2)
-        print(json.dumps(line))
-    # release the device objects while the runtime (and a profiler attached to it) is still alive: nothing is
-    # left for interpreter shutdown to destroy in an arbitrary order
+            rec["gpu_over_cpu"] = round(value / cpu["value"], 2)
+            if scan_info:
+                rec["gpu_over_cpu_with_scan"] = round(rec["value_with_scan"] / cpu["value"], 2)
+            c1 = cpu.get("count_star_threads_1")
+            if c1 is not None:
+                rec["count_star_matches_reference"] = bool(c1 == rec["count_star"])
+            mt = [v for kk, v in cpu.items() if kk.startswith("count_star_threads_") and kk != "count_star_threads_1"]
+            if mt and c1 is not None and any(v != c1 for v in mt):
+                rec["reference_multithreaded_count_differs"] = True
+        if is_ssb and cpu and cpu.get("sample_count_star") and world == 1:
+            # parity at full size: the device's COUNT(*) over the same contiguous samples the reference ran on
+            dev_counts = []
+            m = capi.DeviceMultiplexer(pipe, routing, chunk_size=V, regret_budget=budget,
+                                       init_tuple_count=args.init_tuple_count, log_rounds=False)
+            for s0 in cpu["sample_starts"]:
+                capi.run_resident([m], [(s0 // V, (s0 + cpu["sample_rows_each"]) // V)], reset=True, finish=True)
+                r = capi.finish_many([m])[0]
+                dev_counts.append(int(sum(r["stage_out"][p][k - 1] for p in range(len(paths)))))
+            m.close()
+            rec["sample_count_star_device"] = dev_counts
+            rec["count_star_matches_reference"] = bool(dev_counts == cpu["sample_count_star"])
+    # release the device objects while the runtime (and a profiler attached to it) is still alive
     for m in all_mpxs:
         m.close()
     pipe.close()
     for ht, _ in joins:
         ht.close()
+    del tens
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ssb_skew_q41",
+                    help="ssb_skew_q41 (default; also _q42 _q43 _q31 _q21), job_q18, job_light_01")
+    ap.add_argument("--scale", type=float, default=None,
+                    help="SSB-skew: scale factor per GPU (default 100; with --strong: of the whole job); JOB shapes: "
+                         "fraction of the IMDB cardinalities (default 1)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the ranks split ONE table of --scale")
+    ap.add_argument("--routing", default="adaptive_reinit")
+    ap.add_argument("--enumerator", default="auto",
+                    help="SET join_enumerator; auto = sample (the reference's default) for SSB-skew, each_last_once for "
+                         "the JOB shapes (their plan statistics are not modelled)")
+    ap.add_argument("--regret-budget", type=float, default=0.01)
+    ap.add_argument("--init-tuple-count", type=int, default=1024)
+    ap.add_argument("--atc-multiplier", type=int, default=1)
+    ap.add_argument("--chunk-size", type=int, default=1024, help="STANDARD_VECTOR_SIZE of the host engine")
+    ap.add_argument("--max-join-orders", type=int, default=3, help="SET max_join_orders (BASELINE configs[2]: 3)")
+    ap.add_argument("--executors", type=int, default=0,
+                    help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
+                         "contiguous share of the source chunks -- the counterpart of the reference's worker threads "
+                         "(one PipelineExecutor + MultiplexerState per thread, pipeline.cpp:145-174).  0 (default) = 128 "
+                         "for partitions of more than 65 536 chunks, else 32; 1 = the single-executor trace the parity "
+                         "tests pin against the single-threaded reference")
+    ap.add_argument("--reference-tables", action="store_true",
+                    help="index the build sides exactly as the reference's planner would (perfect table only below its "
+                         "1 M-value cap); default: polr_ht_finalize_auto")
+    ap.add_argument("--host-filter", action="store_true")
+    ap.add_argument("--morsels", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--sync-every-step", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true")
+    ap.add_argument("--pin-path", type=int, default=None, help="measurement aid: make join order P of the bank path 0")
+    ap.add_argument("--cpu-sample-rows", type=int, default=8_000_000,
+                    help="SSB-skew CPU baseline: rows of each of the two contiguous lineorder samples")
+    args = ap.parse_args()
+
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("POLR_DIST_BACKEND", "nccl")
+        if os.environ.get("POLR_SHARE_DEVICE"):
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from polr_amd import capi
+    ctx = capi.Context(local_rank)  # raises without the HIP library / a gfx950 device: no fallback
+    env = {"torch": torch, "dist": dist, "dev": dev, "ctx": ctx, "world": world, "rank": rank}
+    is_ssb = args.workload in SSB_QUERIES
+    scale = args.scale if args.scale is not None else (100.0 if is_ssb else 1.0)
+    head = run_case(args.workload, scale, args, env, args.steps, args.warmup, with_cpu=world == 1 and not args.no_cpu_baseline)
+    subs = []
+    if world == 1 and not args.no_sub_records:
+        saved = (args.executors, args.max_join_orders)
+        for sub, sub_scale in (("job_q18", 1.0), ("job_light_01", 1.0)):
+            if sub == args.workload:
+                continue
+            args.max_join_orders = 8 if saved[1] == 3 else saved[1]  # (the JOB sub-records keep round 1's banks)
+            try:
+                r = run_case(sub, sub_scale, args, env, min(args.steps, 20), min(args.warmup, 3),
+                             with_cpu=not args.no_cpu_baseline)
+            except SystemExit as e:
+                r = {"workload": sub, "error": str(e)}
+            if r is not None:
+                subs.append(r)
+        args.executors, args.max_join_orders = saved
+    if rank == 0:
+        if subs:
+            head["sub_records"] = subs
+        print(json.dumps(head))
     ctx.close()
     if world > 1:
         dist.barrier()

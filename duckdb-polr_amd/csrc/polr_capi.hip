@@ -588,7 +588,9 @@ int polr_ht_finalize_auto(polr_ht *ht, int64_t min_value, int64_t max_value, voi
 	const bool ordered = is_signed ? max_value >= min_value : (uint64_t)max_value >= (uint64_t)min_value;
 	if (ht->kind == KIND_NONE && ht->n_keys == 1 && ordered && ht->n_rows_in > 0) {
 		const uint64_t range = is_signed ? (uint64_t)(max_value - min_value) : (uint64_t)max_value - (uint64_t)min_value;
-		if (range < (1ull << 31) && range / POLR_DENSE_FACTOR <= ht->n_rows_in) {
+		// dense keys of any range, and -- like the reference's planner, plan_comparison_join.cpp:118,125 -- any key
+		// whose range is at most 1 M values (a 125 KB bit table, however few of its bits are set: a filtered dimension)
+		if (range < (1ull << 31) && (range / POLR_DENSE_FACTOR <= ht->n_rows_in || range <= 1000000ull)) {
 			rc = polr_ht_finalize_perfect(ht, min_value, max_value, stream);
 			if (rc != POLR_OK && rc != POLR_E_DUPLICATE) {
 				return rc;
@@ -987,8 +989,8 @@ static void plan_flat(polr_pipeline *p, std::vector<StageDesc> &sd_count) {
 	c.flat = 0;
 	c.n_lds_tables = 0;
 	c.lds_table_dwords = 0;
-	if (c.W != 1) {
-		return; // some join reads its key through a build column
+	if (c.W != 1 || c.k > 6) {
+		return; // some join reads its key through a build column / more joins than the sweep holds in registers
 	}
 	for (uint32_t j = 0; j < c.k; j++) {
 		const polr_ht *ht = p->hts[j];
@@ -1003,14 +1005,14 @@ static void plan_flat(polr_pipeline *p, std::vector<StageDesc> &sd_count) {
 			if (ht->min_value < lo || ht->max_value > hi || ht->range > 0xFFFFFFFFull) {
 				return;
 			}
-		} else if (ht->kind != KIND_S8 || ht->capacity > (1ull << 32)) {
+		} else if (ht->kind != KIND_S8 || ht->capacity > (1ull << 31)) {
 			return;
 		}
 	}
 	const size_t per_wave = polr_pool_flat_wave_bytes(c.k);
 	uint32_t wpb = 4;
 	for (uint32_t w : {16u, 8u}) {
-		if (per_wave * w <= 96u * 1024) {
+		if (per_wave * w <= 120u * 1024) {
 			wpb = w;
 			break;
 		}

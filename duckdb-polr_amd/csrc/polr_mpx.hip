@@ -518,7 +518,7 @@ static uint32_t next_pow2_u32(uint64_t v) {
 	return p;
 }
 
-#define POOL_HEADER_BYTES 128
+#define POOL_HEADER_BYTES 512
 static_assert(sizeof(PoolRun) <= POOL_HEADER_BYTES, "run header");
 
 static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
@@ -574,7 +574,17 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel does not fit on a CU");
 	}
 	occ = std::min(occ, 8);
-	const uint32_t share = std::max<uint32_t>((flags >> 8) & 0xFFu, 1u);
+	uint32_t share = std::max<uint32_t>((flags >> 8) & 0xFFu, 1u);
+	{
+		// (tuning knob: POLR_POOL_SHARE in the environment sizes the grid for 1/share of the device)
+		static const long share_env = [] {
+			const char *v = getenv("POLR_POOL_SHARE");
+			return v ? atol(v) : 0l;
+		}();
+		if (share_env > 0) {
+			share = (uint32_t)share_env;
+		}
+	}
 	if (share > 16) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "device share 1/%u: at most 16 runs side by side", share);
 	}
@@ -605,8 +615,19 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	// unit rings: sized for everything the executors of this run can have in flight (two slots each) plus the EXIT
 	// entries, with a factor of two to spare
 	const uint32_t pool_waves = n_workers * wpb;
-	const uint32_t lo_cap = next_pow2_u32(2ull * ((uint64_t)pool_waves + 8ull * n + pool_waves / 8 + 64) + 1024);
-	const uint32_t hi_cap = next_pow2_u32(4ull * 18 * n + 256);
+	// Rings in use: every ring must have probe waves that serve it.  Ring capacity: a round of U units leaves at most
+	// U / R + 1 entries on a ring; the executors that have rounds in flight (a of them, two rounds each) published them
+	// when at least a executors were still routing, so all their lo units together are at most 8 x pool_waves + 34 a;
+	// a hi round has at most POLR_POOL_HI_TUPLES / 64 units.  Twice that, plus the EXIT entries.
+	uint32_t n_rings = 1;
+	while (n_rings * 2 <= std::min<uint32_t>(POLR_POOL_RINGS, n_workers)) {
+		n_rings *= 2;
+	}
+	const uint64_t R = n_rings;
+	// (+ a round larger than target x 65 536 tuples has tuples / 65 536 units)
+	const uint32_t lo_cap = next_pow2_u32(2ull * ((8ull * pool_waves + 34ull * n + 2ull * (p->n_tuples >> 16)) / R + 2ull * n +
+	                                              pool_waves / R + 16) + 64);
+	const uint32_t hi_cap = next_pow2_u32(2ull * (2ull * n * (POLR_POOL_HI_TUPLES / POLR_POOL_HI_UNIT / R + 1)) + 64);
 	if (!m0->pool_dev || m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap || m0->pool_dirty) {
 		if (m0->pool_dev && (m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap)) {
 			HIPCHK(ctx, hipStreamSynchronize(st));
@@ -614,7 +635,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 			m0->pool_dev = nullptr;
 		}
 		const uint32_t lc = std::max(lo_cap, m0->pool_lo_cap), hc = std::max(hi_cap, m0->pool_hi_cap);
-		const size_t bytes = sizeof(PoolSync) + (size_t)POLR_POOL_RINGS * ((size_t)lc + hc) * sizeof(PoolEntry);
+		const size_t bytes = sizeof(PoolSync) + (size_t)POLR_POOL_RINGS * (2 * (size_t)lc + hc) * sizeof(PoolEntry);
 		if (!m0->pool_dev) {
 			HIPCHK(ctx, hipMalloc((void **)&m0->pool_dev, bytes));
 		}
@@ -631,12 +652,29 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hr->sync = m0->pool_dev;
 	hr->n_exec = n;
 	hr->n_router_blocks = n_router_blocks;
+	hr->n_rings = n_rings;
+	{
+		// (tuning knob: POLR_POOL_UNITS_X in the environment, 1..4)
+		static const long ux_env = [] {
+			const char *v = getenv("POLR_POOL_UNITS_X");
+			return v ? atol(v) : 0l;
+		}();
+		hr->units_x = ux_env >= 1 && ux_env <= 4 ? (uint32_t)ux_env : 4u; // (ring capacities are sized for 4)
+	}
 	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {
-		hr->worker_waves[r] = ((n_workers + POLR_POOL_RINGS - 1 - r) / POLR_POOL_RINGS) * wpb;
+		hr->worker_waves[r] = r < n_rings ? ((n_workers + n_rings - 1 - r) / n_rings) * wpb : 0u;
 	}
 	hr->pool_waves = pool_waves;
 	hr->lo_cap = m0->pool_lo_cap;
 	hr->hi_cap = m0->pool_hi_cap;
+	{
+		// (tuning knob: POLR_POOL_HI_TUPLES in the environment overrides the size up to which a round is latency-critical)
+		static const long hi_env = [] {
+			const char *v = getenv("POLR_POOL_HI_TUPLES");
+			return v ? atol(v) : -1l;
+		}();
+		hr->hi_tuples = hi_env >= 0 ? (uint32_t)std::min<long>(hi_env, POLR_POOL_HI_TUPLES) : POLR_POOL_HI_TUPLES;
+	}
 	hr->routers_done = 0;
 	hr->abort = 0;
 	hr->host_words = nullptr;

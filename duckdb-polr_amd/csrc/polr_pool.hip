@@ -33,13 +33,13 @@ __device__ __forceinline__ void pool_load_run(const PoolRun *run, PoolRun &rh) {
 	rh.sync = (PoolSync *)uni64((uint64_t)run->sync);
 	rh.n_exec = uni(run->n_exec);
 	rh.n_router_blocks = uni(run->n_router_blocks);
-#pragma unroll
-	for (int r = 0; r < POLR_POOL_RINGS; r++) {
-		rh.worker_waves[r] = uni(run->worker_waves[r]);
-	}
 	rh.pool_waves = uni(run->pool_waves);
 	rh.lo_cap = uni(run->lo_cap);
 	rh.hi_cap = uni(run->hi_cap);
+	rh.hi_tuples = uni(run->hi_tuples);
+	rh.n_rings = uni(run->n_rings);
+	rh.units_x = uni(run->units_x);
+	rh.pad = 0;
 	rh.routers_done = 0;
 	rh.abort = 0;
 	rh.host_words = nullptr;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const Poo
                                             uint32_t (&cnt)[K], uint32_t lane) {
 	const ResidentExec *xp = execs + u.exec;
 	unsigned long long *bank = (unsigned long long *)uni64((uint64_t)xp->counts) +
-	                           (size_t)u.slot * POLR_NSHARD * POLR_KMAX + (size_t)ring * POLR_KMAX;
+	                           (size_t)u.slot * POLR_NSHARD * POLR_KMAX + (size_t)(ring & (POLR_POOL_SHARDS - 1u)) * POLR_KMAX;
 	ResidentSync *sync = (ResidentSync *)uni64((uint64_t)xp->sync);
 	if (lane == 0) {
 		unsigned long long seen = 0;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const Poo
 				seen |= atomicAdd(&bank[p], (unsigned long long)cnt[p]);
 			}
 		}
-		atomicAdd(&sync->arrived[u.slot][ring].v, 1ull + (seen >> 63));
+		atomicAdd(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, 1ull + (seen >> 63));
 	}
 #pragma unroll
 	for (int p = 0; p < K; p++) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 		pool_router_wave(execs, run, rh, k, 256, lds, lds_per_wave);
 		return;
 	}
-	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) % POLR_POOL_RINGS;
+	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) & (rh.n_rings - 1u);
 	WaveCtx<W, K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 	c.overflow = false;
 	const StageDesc *stages = uniptr(pipe->stages);
 	uint32_t cur_path = 0xFFFFFFFFu;
-	unsigned long long lo_ticket = ~0ull;
+	unsigned long long lo_ticket = ~0ull, mid_ticket = ~0ull;
 	PoolUnit u;
-	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, u, c.lane)) {
+	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, mid_ticket, u, c.lane)) {
 		if (u.path != cur_path) {
 			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)u.path * POLR_KMAX);
 			uint32_t *dst = (uint32_t *)c.desc;
@@ -200,28 +200,31 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		}
 		__syncthreads();
 	}
-	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) % POLR_POOL_RINGS;
+	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) & (rh.n_rings - 1u);
 	FlatCtx<K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
 	c.sel = uniptr(pipe->sel);
 	c.lds_tables = lds;
-	c.q = lds + table_dwords + (size_t)wave_in_block * lds_per_wave;
+	c.q = (uint16_t *)(lds + table_dwords + (size_t)wave_in_block * lds_per_wave);
 #pragma unroll
 	for (int p = 0; p < K; p++) {
 		c.qsize[p] = c.cnt[p] = 0;
 		c.st[p].keys = nullptr;
 		c.st[p].valid = nullptr;
 		c.st[p].table = nullptr;
-		c.st[p].kind = c.st[p].min32 = c.st[p].range32 = c.st[p].lds_off1 = 0;
-		c.st[p].mask = 0;
+		c.st[p].kind_lds = c.st[p].a = c.st[p].b = 0;
 	}
-	c.in_pos = c.in_end = 0;
+	c.unit_begin = c.in_pos = c.in_end = 0;
+	c.pf_pos = ~0ull;
+	c.pf0 = make_uint4(0, 0, 0, 0);
+	c.pf1 = make_uint4(0, 0, 0, 0);
 	const StageDesc *stages = uniptr(pipe->stages);
 	uint32_t cur_path = 0xFFFFFFFFu;
-	unsigned long long lo_ticket = ~0ull;
+	unsigned long long lo_ticket = ~0ull, mid_ticket = ~0ull;
 	PoolUnit u;
-	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, u, c.lane)) {
+	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, mid_ticket, u, c.lane)) {
+		c.pf_pos = ~0ull; // (a prefetch belongs to one unit of one join order)
 		if (u.path != cur_path) {
 #pragma unroll
 			for (int p = 0; p < K; p++) {
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 			}
 			cur_path = u.path;
 		}
+		c.unit_begin = u.begin;
 		c.in_pos = u.begin;
 		c.in_end = (uint64_t)u.begin + u.count;
 		flat_run_unit<K>(c);

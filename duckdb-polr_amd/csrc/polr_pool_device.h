@@ -10,9 +10,10 @@
 // of one executor therefore run beside the table-sized rounds of the others instead of idling a fixed slice of
 // the grid, and a skewed source range only makes its executor finish later, not its share of the device.
 //
-//   rings     POLR_POOL_RINGS (8) x {hi, lo}: FIFO of 16-byte unit entries.  Worker waves of workgroup b use ring
-//             b % 8 (the workgroups of one XCD under round-robin placement: speed only).  Routers deal the units
-//             of a round round-robin over the rings.  hi = rounds of <= POLR_POOL_HI_TUPLES tuples (exploration
+//   rings     POLR_POOL_RINGS (64) x {hi, lo}: FIFO of 16-byte unit entries.  Worker waves of workgroup b use ring
+//             b % 64; three queues per ring, see PoolRoundOut (64 rings keep the pollers of one control line few: with 8 rings, 512 idle waves per ring answered
+//             every small round with a storm of compare-and-swaps on one word -- measured 8 us per round, serialised over
+//             all executors).  Routers deal the units of a round round-robin over the rings.  hi = rounds of <= POLR_POOL_HI_TUPLES tuples (exploration
 //             slices: latency-critical, taken first), lo = everything else.
 //   entry     two 8-byte granules, each carrying the lap tag of its ticket, written and read with relaxed
 //             agent-scope 8-byte atomics (self-validating, no fences):
@@ -32,7 +33,8 @@
 
 #include "polr_mpx_device.h"
 
-#define POLR_POOL_RINGS 8
+#define POLR_POOL_RINGS 64 // unit queues; counters and arrivals are sharded 8 ways (ring & 7)
+#define POLR_POOL_SHARDS 8
 #define POLR_POOL_HI_TUPLES 4096u // rounds up to this many tuples are latency-critical (exploration slices)
 #define POLR_POOL_HI_UNIT 64u
 #define POLR_POOL_KIND_WORK 1u
@@ -41,7 +43,8 @@
 struct PoolRingCtl { // one 128-byte line each
 	unsigned long long lo_head, pad0[15];
 	unsigned long long lo_tail, pad1[15];
-	unsigned long long hi_head, hi_tail, pad2[14]; // (read together by the pollers)
+	unsigned long long hi_head, hi_tail, pad2[14];   // (read together by the pollers)
+	unsigned long long mid_head, mid_tail, pad3[14];
 };
 
 struct PoolEntry {
@@ -53,14 +56,17 @@ struct PoolSync {
 	PoolRingCtl ctl[POLR_POOL_RINGS];
 	uint32_t lo_cap, hi_cap; // entries per ring (powers of two)
 	uint32_t pad[30];
-	// followed by: PoolEntry lo[POLR_POOL_RINGS][lo_cap], PoolEntry hi[POLR_POOL_RINGS][hi_cap]
+	// followed by: PoolEntry lo[POLR_POOL_RINGS][lo_cap], mid[POLR_POOL_RINGS][lo_cap], hi[POLR_POOL_RINGS][hi_cap]
 };
 
 __device__ __forceinline__ PoolEntry *polr_pool_lo(PoolSync *s, uint32_t ring, uint32_t lo_cap) {
 	return (PoolEntry *)(s + 1) + (size_t)ring * lo_cap;
 }
+__device__ __forceinline__ PoolEntry *polr_pool_mid(PoolSync *s, uint32_t ring, uint32_t lo_cap) {
+	return (PoolEntry *)(s + 1) + (size_t)POLR_POOL_RINGS * lo_cap + (size_t)ring * lo_cap;
+}
 __device__ __forceinline__ PoolEntry *polr_pool_hi(PoolSync *s, uint32_t ring, uint32_t lo_cap, uint32_t hi_cap) {
-	return (PoolEntry *)(s + 1) + (size_t)POLR_POOL_RINGS * lo_cap + (size_t)ring * hi_cap;
+	return (PoolEntry *)(s + 1) + (size_t)2 * POLR_POOL_RINGS * lo_cap + (size_t)ring * hi_cap;
 }
 
 // Per-run header, rewritten by the host with every launch (copied with the executor descriptors).
@@ -68,12 +74,17 @@ struct PoolRun {
 	PoolSync *sync;
 	uint32_t n_exec;
 	uint32_t n_router_blocks;
-	uint32_t worker_waves[POLR_POOL_RINGS]; // probe waves that poll ring r (EXIT entries to publish)
 	uint32_t pool_waves;                    // all probe waves
 	uint32_t lo_cap, hi_cap;                // entries per ring (powers of two), as in *sync
+	uint32_t hi_tuples;                     // rounds of up to this many tuples go to the hi queues
+	uint32_t units_x;                       // a big round is cut into about units_x * pool_waves / (executors routing) units
+	uint32_t pad;
+	uint32_t n_rings;                       // rings in use: a power of two <= min(POLR_POOL_RINGS, probe workgroups), so that
+	                                        // every ring has waves that serve it
 	uint32_t routers_done;                  // device: routers that have finished
 	uint32_t abort;                         // device: a watchdog fired
 	volatile uint32_t *host_words;          // pinned: [2] = 1 when the run was given up
+	uint32_t worker_waves[POLR_POOL_RINGS]; // probe waves that poll ring r (EXIT entries to publish); read in place
 };
 
 __device__ __forceinline__ uint32_t polr_pool_tag(unsigned long long ticket, uint32_t cap) {
@@ -91,25 +102,33 @@ __device__ __forceinline__ unsigned long long polr_pool_g1(uint32_t tag, uint32_
 }
 
 // what a router has decided for one round, as the publisher needs it
+// cls: which queue a round goes to.  0 = hi: a small round (an exploration slice) -- latency-critical, taken first;
+// 1 = mid: a bigger round whose counters the executor's next decision waits for -- taken before ...
+// 2 = lo: a TERMINAL round, after which its executor routes nothing any more (DEFAULT_PATH, INIT_ONCE after its init
+// phase, ADAPTIVE_REINIT below its resistance tolerance: num_cache_flushing_skips = "never again").  Terminal rounds are
+// the bulk of a table-sized run and nobody waits for them: FIFO behind them, an executor in the middle of its
+// explore / exploit windows would sit out the whole backlog at every window.
 struct PoolRoundOut {
-	uint32_t begin, count, path, emit, unit, n_units, hi;
+	uint32_t begin, count, path, emit, unit, n_units, cls;
 };
 
 // unit size of a round: small rounds are spread 64 tuples per wave (the dependent-load chain of a step is the same
 // for 64 and for 512 tuples: more waves in parallel is strictly faster); big rounds are cut so that one executor's
 // round gives every probe wave of its share of the pool a few units, in multiples of `gran` tuples
 __device__ __forceinline__ void polr_pool_size_units(uint64_t tuples, uint32_t pool_waves, uint32_t n_exec, uint32_t gran,
+                                                     uint32_t hi_tuples, uint32_t units_x, bool terminal,
                                                      PoolRoundOut &r) {
-	if (tuples <= POLR_POOL_HI_TUPLES) {
-		r.hi = 1;
+	if (tuples <= hi_tuples) {
+		r.cls = 0;
 		r.unit = POLR_POOL_HI_UNIT;
 	} else {
-		r.hi = 0;
-		uint64_t target = 4ull * pool_waves / (n_exec ? n_exec : 1u);
+		r.cls = terminal ? 2u : 1u;
+		uint64_t target = (uint64_t)units_x * pool_waves / (n_exec ? n_exec : 1u);
 		target = target < 16 ? 16 : target;
 		uint64_t us = (tuples + target - 1) / target;
 		us = ((us + gran - 1) / gran) * gran;
-		r.unit = (uint32_t)(us < gran ? gran : (us > 0x40000000ull ? 0x40000000ull : us));
+		// (never more than 65 536 tuples: the flat pipeline queues 16-bit positions inside the unit)
+		r.unit = (uint32_t)(us < gran ? gran : (us > 65536ull ? 65536ull : us));
 	}
 	r.n_units = (uint32_t)((tuples + r.unit - 1) / r.unit);
 }
@@ -117,7 +136,7 @@ __device__ __forceinline__ void polr_pool_size_units(uint64_t tuples, uint32_t p
 // sum of the 8 arrival shards of a slot (full wave; the same value in every lane)
 __device__ __forceinline__ unsigned long long polr_pool_arrived(ResidentSync *sync, uint32_t slot, uint32_t lane) {
 	unsigned long long v = 0;
-	if (lane < POLR_POOL_RINGS) {
+	if (lane < POLR_POOL_SHARDS) {
 		v = __hip_atomic_load(&sync->arrived[slot][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	for (int d = 4; d > 0; d >>= 1) {
@@ -155,23 +174,28 @@ __device__ __forceinline__ uint64_t polr_pool_absorb(DevMpx *m, DevMpx *mg, unsi
 __device__ __forceinline__ void polr_pool_publish(const PoolRun &run, PoolSync *sync, uint32_t exec, uint32_t slot,
                                                   const PoolRoundOut &r, uint32_t rot, uint32_t lane) {
 	const uint32_t lo_cap = run.lo_cap, hi_cap = run.hi_cap;
-	// ring (rot + u) % 8 gets unit u: n_r units for ring r
+	// ring (rot + u) % R gets unit u: lane r reserves the n_r tickets of ring r (one instruction for all rings)
+	static_assert(POLR_POOL_RINGS == 64, "one lane per ring");
+	const uint32_t R = run.n_rings;
 	unsigned long long base = 0;
-	if (lane < POLR_POOL_RINGS) {
-		const uint32_t first = (lane + POLR_POOL_RINGS - (rot & 7u)) & 7u; // smallest u dealt to ring `lane`
-		const uint32_t n_r = r.n_units > first ? (r.n_units - first + 7u) / 8u : 0u;
+	if (lane < R) {
+		const uint32_t first = (lane + R - (rot & (R - 1u))) & (R - 1u); // smallest u dealt to ring `lane`
+		const uint32_t n_r = r.n_units > first ? (r.n_units - first + R - 1u) / R : 0u;
 		if (n_r) {
-			base = atomicAdd(r.hi ? &sync->ctl[lane].hi_tail : &sync->ctl[lane].lo_tail, (unsigned long long)n_r);
+			base = atomicAdd(r.cls == 0 ? &sync->ctl[lane].hi_tail
+			                            : (r.cls == 1 ? &sync->ctl[lane].mid_tail : &sync->ctl[lane].lo_tail),
+			                 (unsigned long long)n_r);
 		}
 	}
 	for (uint32_t u0 = 0; u0 < r.n_units; u0 += 64) {
 		const uint32_t u = u0 + lane;
-		const uint32_t ring = (rot + u) & 7u;
+		const uint32_t ring = (rot + u) & (R - 1u);
 		const unsigned long long ring_base = __shfl(base, ring, 64);
 		if (u < r.n_units) {
-			const unsigned long long ticket = ring_base + u / 8u;
-			const uint32_t cap = r.hi ? hi_cap : lo_cap;
-			PoolEntry *e = (r.hi ? polr_pool_hi(sync, ring, lo_cap, hi_cap) : polr_pool_lo(sync, ring, lo_cap)) +
+			const unsigned long long ticket = ring_base + u / R;
+			const uint32_t cap = r.cls == 0 ? hi_cap : lo_cap;
+			PoolEntry *e = (r.cls == 0 ? polr_pool_hi(sync, ring, lo_cap, hi_cap)
+			                           : (r.cls == 1 ? polr_pool_mid(sync, ring, lo_cap) : polr_pool_lo(sync, ring, lo_cap))) +
 			               (ticket & (cap - 1u));
 			const uint32_t tag = polr_pool_tag(ticket, cap);
 			const uint32_t ub = r.begin + u * r.unit;
@@ -184,19 +208,19 @@ __device__ __forceinline__ void polr_pool_publish(const PoolRun &run, PoolSync *
 	}
 }
 
-// one EXIT entry per probe wave of every ring (the router that finishes last)
-__device__ __forceinline__ void polr_pool_publish_exit(const PoolRun &run, PoolSync *sync, uint32_t lane) {
-	const uint32_t lo_cap = run.lo_cap;
-	for (uint32_t ring = 0; ring < POLR_POOL_RINGS; ring++) {
-		const uint32_t n = run.worker_waves[ring];
-		if (n == 0) {
-			continue;
-		}
-		unsigned long long base = 0;
-		if (lane == 0) {
-			base = atomicAdd(&sync->ctl[ring].lo_tail, (unsigned long long)n);
-		}
-		base = __shfl(base, 0, 64);
+// one EXIT entry per probe wave of every ring (the router that finishes last); run: the header in global memory
+__device__ __forceinline__ void polr_pool_publish_exit(const PoolRun *run, const PoolRun &rh, PoolSync *sync, uint32_t lane) {
+	const uint32_t lo_cap = rh.lo_cap;
+	const uint32_t n_mine = lane < rh.n_rings ? run->worker_waves[lane] : 0u; // lane r: ring r
+	unsigned long long base_mine = 0;
+	if (n_mine) {
+		base_mine = atomicAdd(&sync->ctl[lane].lo_tail, (unsigned long long)n_mine);
+		// every probe wave leaves holding one mid ticket that no unit will be written for: the next run starts behind them
+		(void)atomicAdd(&sync->ctl[lane].mid_tail, (unsigned long long)n_mine);
+	}
+	for (uint32_t ring = 0; ring < rh.n_rings; ring++) {
+		const uint32_t n = __shfl(n_mine, ring, 64);
+		const unsigned long long base = __shfl(base_mine, ring, 64);
 		for (uint32_t i = lane; i < n; i += 64) {
 			const unsigned long long ticket = base + i;
 			PoolEntry *e = polr_pool_lo(sync, ring, lo_cap) + (ticket & (lo_cap - 1u));
@@ -227,43 +251,69 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 	return true;
 }
 
+// one lane: take a ticket of a non-blocking queue if it has one (compare-and-swap on its head while head < tail) and
+// read its entry (being written by the router that reserved it)
+__device__ __forceinline__ bool polr_pool_try_claim(unsigned long long *head, unsigned long long *tail, PoolEntry *entries,
+                                                    uint32_t cap, unsigned long long &g0, unsigned long long &g1,
+                                                    uint32_t &tag) {
+	const unsigned long long hh = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long ht = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (hh >= ht) {
+		return false;
+	}
+	unsigned long long expect = hh;
+	if (!__hip_atomic_compare_exchange_strong(head, &expect, hh + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+	                                          __HIP_MEMORY_SCOPE_AGENT)) {
+		return false;
+	}
+	PoolEntry *e = entries + (hh & (cap - 1u));
+	tag = polr_pool_tag(hh, cap);
+	const unsigned long long t1 = wall_clock64();
+	while (true) {
+		g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) || wall_clock64() - t1 > POLR_RES_TIMEOUT_TICKS) {
+			break;
+		}
+		__builtin_amdgcn_s_sleep(1);
+	}
+	return true;
+}
+
 // Take the next unit for this wave (all lanes get the same answer).  lo_ticket: the lo ticket this wave holds
 // (~0ull: none) -- kept across calls, because a wave that holds a not-yet-written lo ticket serves hi units meanwhile.
 // Returns false when the wave has to leave (EXIT entry, abort or watchdog).
 __device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run, PoolSync *sync, uint32_t ring, uint32_t lo_cap,
-                                                    uint32_t hi_cap, unsigned long long &lo_ticket, PoolUnit &u,
-                                                    uint32_t lane) {
+                                                    uint32_t hi_cap, unsigned long long &lo_ticket,
+                                                    unsigned long long &mid_ticket, PoolUnit &u, uint32_t lane) {
 	PoolRingCtl *ctl = &sync->ctl[ring];
 	uint32_t spins = 0;
 	while (true) {
 		unsigned long long g0 = 0, g1 = 0;
 		uint32_t tag = 0, got = 0;
 		if (lane == 0) {
-			// (1) latency-critical units first: only while the hi queue is not empty, never blocking
-			const unsigned long long hh = __hip_atomic_load(&ctl->hi_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const unsigned long long ht = __hip_atomic_load(&ctl->hi_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (hh < ht) {
-				unsigned long long expect = hh;
-				if (__hip_atomic_compare_exchange_strong(&ctl->hi_head, &expect, hh + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-				                                         __HIP_MEMORY_SCOPE_AGENT)) {
-					// ticket hh is ours; its entry is being written by the router that reserved it
-					PoolEntry *e = polr_pool_hi(sync, ring, lo_cap, hi_cap) + (hh & (hi_cap - 1u));
-					tag = polr_pool_tag(hh, hi_cap);
-					const unsigned long long t1 = wall_clock64();
-					while (true) {
-						g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if (((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) ||
-						    wall_clock64() - t1 > POLR_RES_TIMEOUT_TICKS) {
-							break;
-						}
-						__builtin_amdgcn_s_sleep(1);
-					}
-					got = 1;
+			// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
+			got = polr_pool_try_claim(&ctl->hi_head, &ctl->hi_tail, polr_pool_hi(sync, ring, lo_cap, hi_cap), hi_cap, g0, g1, tag)
+			          ? 1u
+			          : 0u;
+			if (!got) {
+				// (2) the mid queue: hold one ticket, look whether its entry has been written.  (Blocking tickets, like lo:
+				// compare-and-swap claims of the hundreds of units of an exploit round were measured slower than FIFO
+				// blocking behind them.  A mid unit waits at most for the unit its ticket holder is busy with.)
+				if (mid_ticket == ~0ull) {
+					mid_ticket = atomicAdd(&ctl->mid_head, 1ull);
+				}
+				PoolEntry *e = polr_pool_mid(sync, ring, lo_cap) + (mid_ticket & (lo_cap - 1u));
+				tag = polr_pool_tag(mid_ticket, lo_cap);
+				g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) {
+					got = 3;
+					mid_ticket = ~0ull;
 				}
 			}
 			if (!got) {
-				// (2) the lo queue: hold one ticket, look whether its entry has been written
+				// (3) the lo queue: hold one ticket, look whether its entry has been written
 				if (lo_ticket == ~0ull) {
 					lo_ticket = atomicAdd(&ctl->lo_head, 1ull);
 				}
@@ -467,7 +517,16 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			r.count = (uint32_t)vr->count;
 			r.path = vr->path;
 			r.emit = vr->emit;
-			polr_pool_size_units(r.count, rh.pool_waves, rh.n_exec, gran, r);
+			// a round is cut for the executors that are still routing: the last ones get the whole pool
+			uint32_t active = rh.n_exec;
+			if (r.count > rh.hi_tuples) {
+				// (routers_done counts executors that have finished ROUTING; their terminal rounds may still
+				// be queued, which is what the lo queue is for)
+				const uint32_t done_now = __hip_atomic_load(&run->routers_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				active = done_now < rh.n_exec ? rh.n_exec - done_now : 1u;
+			}
+			const bool terminal = ((volatile DevMpx *)m)->core.num_cache_flushing_skips == polr::kIdxMax;
+			polr_pool_size_units(r.count, rh.pool_waves, active, gran, rh.hi_tuples, rh.units_x, terminal, r);
 			if (pass == 1) {
 				__builtin_amdgcn_wave_barrier();
 				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
@@ -557,6 +616,6 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		last = before + 1u == rh.n_exec ? 1u : 0u;
 	}
 	if (__builtin_amdgcn_readfirstlane(last)) {
-		polr_pool_publish_exit(rh, sync, lane);
+		polr_pool_publish_exit(run, rh, sync, lane);
 	}
 }

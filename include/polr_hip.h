@@ -113,7 +113,8 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream);
 int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, void *stream);
 /* Let the device pick the index: a single integer key whose value range [min,max] (the build column's
  * statistics, as PerfectHashJoinStats carries them: build_min / build_max) is at most POLR_DENSE_FACTOR x
- * the build rows becomes a perfect table (1 bit per key value: 3 M dense keys = 375 KB, L2-resident, where a
+ * the build rows -- or at most 1 000 000 values, the reference planner's own bound (plan_comparison_join.cpp:118,125) --
+ * becomes a perfect table (1 bit per key value: 3 M dense keys = 375 KB, L2-resident, where a
  * bucket table would cost one random 64-B HBM line per probe) -- the reference's own perfect-hash idea without
  * its 1 M-value cap (perfect_hash_join_executor.cpp:25-50), which was sized for CPU caches; anything else,
  * and a range with a duplicate key, becomes a hash table.  Match sets are identical either way; *kind_out

@@ -31,7 +31,7 @@ def table_lines(workdir, name, cols, pk=None):
     return lines
 
 
-def time_polar_pipeline(tables, query, settings, threads, repeat=5):
+def time_polar_pipeline(tables, query, settings, threads, repeat=5, pk=None):
     """Loads `tables` ({name: {col: ndarray}}), runs `query` `repeat` times with POLAR on and
     PRAGMA enable_measure_pipeline; returns the list of POLAR-pipeline durations in ms
     (Pipeline::Schedule -> Finalize, src/parallel/pipeline.cpp:138,247-263) and the wall ms of each run."""
@@ -39,7 +39,7 @@ def time_polar_pipeline(tables, query, settings, threads, repeat=5):
     try:
         lines = []
         for name, cols in tables.items():
-            lines += table_lines(workdir, name, cols)
+            lines += table_lines(workdir, name, cols, pk=(pk or {}).get(name))
         lines.append("sql SET threads TO %d" % threads)
         for s in settings:
             lines.append("sql " + s)

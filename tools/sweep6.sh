@@ -1,0 +1,15 @@
+run() { echo "== $ARGS $*"; env "$@" timeout -k 10 200 python bench.py $ARGS --no-sub-records --no-cpu-baseline 2>gpurun_out/sweep_err.txt | python -c "
+import json,sys
+r=json.loads(sys.stdin.read())
+print('RESULT ms/step', r['ms_per_step'], 'kernel_ms', r['roofline']['kernel_ms_per_step'], 'Gt/s', round(r['value']/1e9,2), 'rounds', r['routing_rounds'], 'E', r['config']['executors_per_gpu'], 'frac', r['roofline']['frac'], 'B/t', r['roofline']['algorithmic_bytes_per_tuple'], 'inter', r['total_intermediates'])
+" || tail -3 gpurun_out/sweep_err.txt; }
+ARGS="--scale 100 --steps 10 --warmup 3 --executors 1 --routing default_path --pin-path 3"; run A=1
+ARGS="--scale 100 --steps 10 --warmup 3 --executors 1 --routing default_path"; run A=1
+for e in 128 256 512; do
+ARGS="--scale 100 --steps 10 --warmup 3 --executors $e"; run A=1
+done
+ARGS="--workload job_light_01 --steps 20 --warmup 3 --executors 8"; run A=1
+ARGS="--workload job_light_01 --steps 20 --warmup 3 --executors 32"; run A=1
+ARGS="--workload job_light_01 --steps 20 --warmup 3 --executors 128 --routing opportunistic"; run A=1
+ARGS="--workload job_light_01 --steps 20 --warmup 3 --executors 128 --routing dynamic"; run A=1
+ARGS="--workload job_q18 --steps 20 --warmup 3 --executors 32"; run A=1
