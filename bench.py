@@ -324,7 +324,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     budget = args.regret_budget
     if routing == "exponential_backoff":
         budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
-    want_e = args.executors if args.executors > 0 else (128 if n_chunks > 65536 else 32)
+    want_e = args.executors if args.executors > 0 else (256 if n_chunks > 65536 else 32)
     E = max(1, min(want_e, n_chunks))
     P = max(1, args.streams) if not args.sync_every_step else 1
     sets = []
@@ -537,7 +537,7 @@ def main():
     ap.add_argument("--executors", type=int, default=0,
                     help="concurrent pipeline executors per GPU, each with its own multiplexer state and its own "
                          "contiguous share of the source chunks -- the counterpart of the reference's worker threads "
-                         "(one PipelineExecutor + MultiplexerState per thread, pipeline.cpp:145-174).  0 (default) = 128 "
+                         "(one PipelineExecutor + MultiplexerState per thread, pipeline.cpp:145-174).  0 (default) = 256 "
                          "for partitions of more than 65 536 chunks, else 32; 1 = the single-executor trace the parity "
                          "tests pin against the single-threaded reference")
     ap.add_argument("--reference-tables", action="store_true",

@@ -660,6 +660,16 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 			return v ? atol(v) : 0l;
 		}();
 		hr->units_x = ux_env >= 1 && ux_env <= 4 ? (uint32_t)ux_env : 4u; // (ring capacities are sized for 4)
+		// (tuning knob: POLR_POOL_HI_UNIT, tuples per unit of a small round: 64 .. 1024, a multiple of 64)
+		static const long hu_env = [] {
+			const char *v = getenv("POLR_POOL_HI_UNIT");
+			return v ? atol(v) : 0l;
+		}();
+		// default: one step of the pipeline's stage 0 (flat: 512 tuples, generic: a wide step of 256).  64-tuple units
+		// finish a lone small round soonest, but a unit costs its wave the same chain of dependent round trips whatever
+		// its size, and with hundreds of executors exploring that wave time is what the pool runs out of (measured on
+		// the SF100 run: 2.29 ms with 64-tuple units, 1.77 ms with 512)
+		hr->hi_unit = hu_env >= 64 && hu_env <= 1024 && hu_env % 64 == 0 ? (uint32_t)hu_env : (flat ? 512u : 256u);
 	}
 	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {
 		hr->worker_waves[r] = r < n_rings ? ((n_workers + n_rings - 1 - r) / n_rings) * wpb : 0u;

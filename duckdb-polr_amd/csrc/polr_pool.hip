@@ -39,7 +39,7 @@ __device__ __forceinline__ void pool_load_run(const PoolRun *run, PoolRun &rh) {
 	rh.hi_tuples = uni(run->hi_tuples);
 	rh.n_rings = uni(run->n_rings);
 	rh.units_x = uni(run->units_x);
-	rh.pad = 0;
+	rh.hi_unit = uni(run->hi_unit);
 	rh.routers_done = 0;
 	rh.abort = 0;
 	rh.host_words = nullptr;

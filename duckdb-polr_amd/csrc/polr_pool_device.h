@@ -36,7 +36,7 @@
 #define POLR_POOL_RINGS 64 // unit queues; counters and arrivals are sharded 8 ways (ring & 7)
 #define POLR_POOL_SHARDS 8
 #define POLR_POOL_HI_TUPLES 4096u // rounds up to this many tuples are latency-critical (exploration slices)
-#define POLR_POOL_HI_UNIT 64u
+#define POLR_POOL_HI_UNIT 64u // smallest unit of a small round (ring capacities are sized for it)
 #define POLR_POOL_KIND_WORK 1u
 #define POLR_POOL_KIND_EXIT 2u
 
@@ -78,7 +78,7 @@ struct PoolRun {
 	uint32_t lo_cap, hi_cap;                // entries per ring (powers of two), as in *sync
 	uint32_t hi_tuples;                     // rounds of up to this many tuples go to the hi queues
 	uint32_t units_x;                       // a big round is cut into about units_x * pool_waves / (executors routing) units
-	uint32_t pad;
+	uint32_t hi_unit;                       // tuples per unit of a small round
 	uint32_t n_rings;                       // rings in use: a power of two <= min(POLR_POOL_RINGS, probe workgroups), so that
 	                                        // every ring has waves that serve it
 	uint32_t routers_done;                  // device: routers that have finished
@@ -116,11 +116,11 @@ struct PoolRoundOut {
 // for 64 and for 512 tuples: more waves in parallel is strictly faster); big rounds are cut so that one executor's
 // round gives every probe wave of its share of the pool a few units, in multiples of `gran` tuples
 __device__ __forceinline__ void polr_pool_size_units(uint64_t tuples, uint32_t pool_waves, uint32_t n_exec, uint32_t gran,
-                                                     uint32_t hi_tuples, uint32_t units_x, bool terminal,
+                                                     uint32_t hi_tuples, uint32_t units_x, uint32_t hi_unit, bool terminal,
                                                      PoolRoundOut &r) {
 	if (tuples <= hi_tuples) {
 		r.cls = 0;
-		r.unit = POLR_POOL_HI_UNIT;
+		r.unit = hi_unit;
 	} else {
 		r.cls = terminal ? 2u : 1u;
 		uint64_t target = (uint64_t)units_x * pool_waves / (n_exec ? n_exec : 1u);
@@ -526,7 +526,7 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 				active = done_now < rh.n_exec ? rh.n_exec - done_now : 1u;
 			}
 			const bool terminal = ((volatile DevMpx *)m)->core.num_cache_flushing_skips == polr::kIdxMax;
-			polr_pool_size_units(r.count, rh.pool_waves, active, gran, rh.hi_tuples, rh.units_x, terminal, r);
+			polr_pool_size_units(r.count, rh.pool_waves, active, gran, rh.hi_tuples, rh.units_x, rh.hi_unit, terminal, r);
 			if (pass == 1) {
 				__builtin_amdgcn_wave_barrier();
 				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {

@@ -1,0 +1,157 @@
+"""The SSB-skew queries on the load.sql-transformed data (polr_amd.ssb_skew) with the reference's DEFAULT enumerator
+(`sample`) -- against the reference's own runs (tests/golden/ssb_skew_sample.json, tests/golden/make_golden_ssb_skew.py):
+ALTERNATE matrix, COUNT(*), and the routing traces of the six deterministic strategies, for Q4.1 / Q4.2 / Q4.3 / Q3.1 /
+Q2.1 and two bank sizes.  CPU: the oracle.  GPU (-m gpu): the device through the C ABI -- the FLAT pipeline with
+LDS-resident bit tables inside the pool launch (one executor = the reference's single-threaded trace), per-round
+launches of the generic kernel, and many executors sharing the pool (row counts only: traces are per executor)."""
+import numpy as np
+import pytest
+
+import common
+from common import orc
+from polr_amd import host as phost
+from polr_amd import ssb_skew
+
+GOLD = common.load_golden("ssb_skew_sample")
+ROUTINGS = ["init_once", "opportunistic", "adaptive_reinit", "dynamic", "exponential_backoff", "default_path"]
+CASES = sorted(c for c in GOLD["cases"] if GOLD["cases"][c]["paths"] is not None)
+_wl = {}
+
+
+def workload(case):
+    c = GOLD["cases"][case]
+    if c["query"] not in _wl:
+        _wl[c["query"]] = ssb_skew.workload(c["query"], **GOLD["shape"])
+    return _wl[c["query"]], np.asarray(c["paths"], dtype=np.int32), c
+
+
+def budget(routing, n_rows):
+    return n_rows / 10240.0 / 10 / 1 if routing == "exponential_backoff" else 0.01  # polar_config.cpp:115-120
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case):
+    wl, paths, c = workload(case)
+    pcols, pvalid, joins = common.oracle_joins(wl)
+    n = len(pcols[0])
+    res = orc.run_pipeline(pcols, joins, paths, routing="alternate", caching=False, collect_output=False)
+    assert np.array_equal(res["alt_matrix"], np.asarray(c["alternate"]["matrix"], dtype=np.uint64))
+    assert res["num_intermediates"] == c["alternate"]["intms"]
+    for routing in ROUTINGS:
+        res = orc.run_pipeline(pcols, joins, paths, routing=routing, caching=False, collect_output=False,
+                               regret_budget=budget(routing, n))
+        g = c["routing"][routing]
+        assert res["num_output_rows"] == c["count_star"], routing
+        assert list(res["intermediates_per_round"]) == g["rounds"], routing
+        assert res["num_intermediates"] == g["intms"], routing
+        assert res["input_tuple_count_per_path"][:len(paths)] == g["tuple_counts"], routing
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launch", ["pool", "rounds"])
+@pytest.mark.parametrize("case", CASES)
+def test_device_matches_reference(gpu_ctx, case, launch):
+    from polr_amd import capi
+    wl, paths, c = workload(case)
+    # the bank the host mirror enumerates IS the reference's (also checked on the CPU by test_sample_enumerator.py)
+    k = len(wl["joins"])
+    gen = phost.generate_join_orders("sample", 4, [0] * k, [[j["key_src"][0][1]] for j in wl["joins"]], [1] * k,
+                                     max_join_orders=c["max_join_orders"], node_info=c["node_info"])
+    assert gen[0].tolist() == paths.tolist()
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    info = pipe.launch_info(False)
+    assert info["flat"] == 1 and info["lds_tables"] >= 1  # single-key unique-match joins on probe columns
+    n_chunks = (n + 1023) // 1024
+    P = len(paths)
+    for routing in ["alternate"] + ROUTINGS:
+        mpx = capi.DeviceMultiplexer(pipe, routing, regret_budget=budget(routing, n), max_log_rounds=1 << 16)
+        if launch == "pool":
+            capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+        else:
+            mpx.run(0, n_chunks)
+        st = mpx.finish()
+        _, _, inter = mpx.fetch_log()
+        if routing == "alternate":
+            assert np.array_equal(inter.reshape(-1, P), np.asarray(c["alternate"]["matrix"], dtype=np.uint64))
+            assert st["num_intermediates"] == c["alternate"]["intms"]
+            assert st["stage_out"][0][k - 1] == c["count_star"]  # only path 0 forwards its output
+        else:
+            g = c["routing"][routing]
+            assert list(inter) == g["rounds"], routing
+            assert st["num_intermediates"] == g["intms"], routing
+            assert st["input_tuple_count_per_path"] == g["tuple_counts"], routing
+            assert sum(st["stage_out"][p][k - 1] for p in range(P)) == c["count_star"], routing
+        mpx.close()
+    pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_exec", [3, 16, 97])
+@pytest.mark.parametrize("routing", ["adaptive_reinit", "dynamic", "opportunistic", "init_once"])
+def test_pool_executors_cover_every_tuple_once(gpu_ctx, routing, n_exec):
+    """many executors share the pool of probe waves: whatever the routers decide and whichever wave takes which unit,
+    every tuple is probed exactly once and COUNT(*) is the reference's; per-executor traces equal single-executor
+    runs over the same chunk ranges (an executor's decisions depend on its own counters only)"""
+    from polr_amd import capi
+    wl, paths, c = workload("q4.1/3")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    k, P = len(wl["joins"]), len(paths)
+    mpxs = [capi.DeviceMultiplexer(pipe, routing, regret_budget=budget(routing, n), max_log_rounds=1 << 14)
+            for _ in range(n_exec)]
+    ranges = [((e * n_chunks) // n_exec, ((e + 1) * n_chunks) // n_exec) for e in range(n_exec)]
+    capi.run_resident(mpxs, ranges, reset=True, finish=True)
+    stats = capi.finish_many(mpxs)
+    assert sum(sum(st["stage_out"][p][k - 1] for p in range(P)) for st in stats) == c["count_star"]
+    assert sum(sum(st["input_tuple_count_per_path"]) for st in stats) == n
+    # spot-check three executors against single-executor runs of their ranges
+    solo = capi.DeviceMultiplexer(pipe, routing, regret_budget=budget(routing, n), max_log_rounds=1 << 14)
+    for e in sorted({0, n_exec // 2, n_exec - 1}):
+        capi.run_resident([solo], [ranges[e]], reset=True, finish=True)
+        want = solo.finish()
+        _, _, want_log = solo.fetch_log()
+        _, _, got_log = mpxs[e].fetch_log()
+        assert list(got_log) == list(want_log), (routing, e)
+        assert stats[e]["num_intermediates"] == want["num_intermediates"]
+        assert stats[e]["path_resistances"] == want["path_resistances"]
+    solo.close()
+    for m in mpxs:
+        m.close()
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_two_pool_runs_side_by_side(gpu_ctx):
+    """POLR_RUN_SHARE: two runs on two streams, half the device each, in flight together -- each a pool of its own
+    (own rings, own routers); both traces equal the single run's"""
+    import ctypes as C
+    from polr_amd import capi
+    wl, paths, c = workload("q4.1/3")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    ref = capi.DeviceMultiplexer(pipe, "adaptive_reinit", max_log_rounds=1 << 14)
+    capi.run_resident([ref], [(0, n_chunks)], reset=True, finish=True)
+    want = ref.finish()
+    _, _, want_log = ref.fetch_log()
+    a = capi.DeviceMultiplexer(pipe, "adaptive_reinit", max_log_rounds=1 << 14)
+    b = capi.DeviceMultiplexer(pipe, "adaptive_reinit", max_log_rounds=1 << 14)
+    for _ in range(3):
+        capi.run_resident([a], [(0, n_chunks)], reset=True, finish=True, share=2)
+        capi.run_resident([b], [(0, n_chunks)], reset=True, finish=True, share=2)
+    for m in (a, b):
+        st = m.finish()
+        _, _, log = m.fetch_log()
+        assert list(log) == list(want_log)
+        assert st["num_intermediates"] == want["num_intermediates"]
+    for m in (ref, a, b):
+        m.close()
+    pipe.close()
