@@ -208,8 +208,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         n_total = z["n_lo"] * (1 if args.strong else world)
         wl0 = ssb_skew.workload(query, sf=scale, n_lo=n_total, host_probe=False)
         inst = wl0["instance"]
-        lo, hi = (rank * n_total) // world, ((rank + 1) * n_total) // world
-        lo, hi = (lo // V) * V, ((hi // V) * V if rank + 1 < world else hi)
+        lo, hi = pdist.probe_partition(n_total, world, rank, V)
         names = list(ssb_skew.PROBE_COLS)
         cols_t = inst.lineorder_torch(lo, hi, dev, cols=names)
         tens = [cols_t[c] for c in names]
@@ -267,24 +266,26 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         joins = capi.build_joins(ctx, wl0, auto=not args.reference_tables)
     bcast_bytes = 0
     if world > 1:
-        new_joins = []
-
-        def wrap(buf):
-            return torch.as_tensor(_DevBuf(buf[0], buf[1]), device=dev)
-
-        for x in range(k):
-            exported = joins[x][0].export() if rank == 0 else None
-
-            def alloc_like(meta):
-                ht = capi.HashTable.alloc_like(ctx, meta)
-                return ht, ht.export()[1]
-
-            ht, nbytes = pdist.broadcast_table(dist, torch, dev, rank, exported, alloc_like, wrap)
-            bcast_bytes += nbytes
-            if rank != 0:
-                new_joins.append((ht, wl0["joins"][x]["key_src"]))
-        if rank != 0:
-            joins = new_joins
+        # the path's one exchange step, in the product: polr_bcast_build (librccl, ncclBroadcast over xGMI) -- rank 0's
+        # finalized tables to every rank.  torch.distributed only carries the 128-byte communicator id.
+        # (POLR_DIST_BACKEND=gloo rehearsals on one GPU cannot form an RCCL communicator: they build locally)
+        if env.get("comm") is None and os.environ.get("POLR_DIST_BACKEND", "nccl") == "nccl":
+            idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            env["comm"] = capi.Comm(ctx, bytes(idt.cpu().numpy().tobytes()), world, rank)
+        comm = env.get("comm")
+        if comm is not None:
+            before = comm.bytes_broadcast()
+            got = []
+            for x in range(k):
+                ht = comm.bcast_build(joins[x][0] if rank == 0 else None, root=0)
+                got.append((ht, wl0["joins"][x]["key_src"]))
+            joins = got
+            bcast_bytes = comm.bytes_broadcast() - before
+        elif rank != 0:
+            joins = capi.build_joins(ctx, wl0, auto=not args.reference_tables)
         torch.cuda.synchronize()
     t_build = time.time() - t_build0
     for x in range(k):

@@ -31,6 +31,7 @@ EXPORTS = [
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_morsels",
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
+    "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
 ]
 
 
@@ -165,6 +166,12 @@ def load():
     L.polr_mpx_run_resident_morsels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
+    L.polr_comm_get_unique_id.argtypes = [vp]
+    L.polr_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, P(vp)]
+    L.polr_bcast_build.argtypes = [vp, P(vp), C.c_int, vp]
+    L.polr_comm_bytes_broadcast.argtypes = [vp, P(u64)]
+    L.polr_comm_destroy.argtypes = [vp]
+    L.polr_comm_destroy.restype = None
     _lib = L
     return L
 
@@ -610,6 +617,53 @@ def finish_many(mpxs):
     ctx = mpxs[0].ctx
     ctx.check(ctx.L.polr_mpx_finish_many(hs, n, stats))
     return [_stats_dict(stats[i], mpxs[i].pipe.n_paths, mpxs[i].pipe.k) for i in range(n)]
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """polr_comm_get_unique_id: 128 bytes made on ONE rank, to be shipped to the others out of band"""
+    L = load()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = L.polr_comm_get_unique_id(buf)
+    if rc != OK:
+        raise PolrError(rc, "polr_comm_get_unique_id failed (is librccl.so present?)")
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of the library (one rank per GPU) for polr_bcast_build, the path's one exchange step"""
+
+    def __init__(self, ctx, unique_id, world_size, rank):
+        self.ctx = ctx
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        ctx.check(ctx.L.polr_comm_create(ctx.h, buf, world_size, rank, C.byref(h)))
+        self.h = h
+        self.rank = rank
+
+    def bcast_build(self, ht, root=0, stream=None):
+        """root: ht is the finalized HashTable to send (returned unchanged); other ranks: pass None, get a new one"""
+        h = C.c_void_p(ht.h.value if ht is not None else None)
+        self.ctx.check(self.ctx.L.polr_bcast_build(self.h, C.byref(h), root, stream))
+        return ht if self.rank == root else HashTable(self.ctx, h)
+
+    def bytes_broadcast(self):
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.L.polr_comm_bytes_broadcast(self.h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.h:
+            self.ctx.L.polr_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def build_joins(ctx, wl, auto=False):

@@ -16,6 +16,17 @@ def probe_partition_seed(base_seed, rank):
     return base_seed if rank == 0 else base_seed + 7919 * rank
 
 
+def probe_partition(n_total, world, rank, chunk_size=1024):
+    """rows [lo, hi) of the probe table that rank `rank` of `world` owns: contiguous ranges in scan order (for SSB-skew:
+    contiguous lo_orderkey ranges, so the skew phases stay intact per GPU -- SURVEY.md 8(e)), cut at source-chunk
+    boundaries so that every rank sees whole chunks; the ranges tile [0, n_total) exactly"""
+    lo = (rank * n_total) // world
+    hi = ((rank + 1) * n_total) // world
+    lo = (lo // chunk_size) * chunk_size
+    hi = (hi // chunk_size) * chunk_size if rank + 1 < world else n_total
+    return lo, hi
+
+
 def broadcast_table(dist, torch, device, rank, exported, alloc_like, wrap):
     """Replicate one finalized build side from rank 0.
 

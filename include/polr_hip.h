@@ -147,6 +147,22 @@ int polr_ht_export(const polr_ht *ht, void *meta, uint64_t *meta_bytes, void **d
                    uint32_t *n_buffers);
 int polr_ht_alloc_like(polr_ctx *ctx, const void *meta, uint64_t meta_bytes, polr_ht **out);
 
+/* ---- multi-GPU: the one exchange step of the path ----------------------------------
+ * One POLAR pipeline per GPU (own multiplexer state, own probe partition) is the counterpart of one PipelineExecutor
+ * per worker thread (src/parallel/pipeline.cpp:145-174); the only data every pipeline needs and only one has is the
+ * finalized build side (JoinHashTable::Finalize, src/execution/join_hashtable.cpp:324-377).  polr_bcast_build ships
+ * it from the rank that built it to all others with ncclBroadcast over xGMI (RCCL, loaded on first use): metadata,
+ * then every device buffer in place.  Collective: every rank calls it, in the same order.  root: *ht is the table to
+ * send; other ranks: *ht receives a new table (caller destroys it).  The 128-byte id comes from
+ * polr_comm_get_unique_id on one rank and reaches the others out of band (the host engine's own channel). */
+#define POLR_COMM_ID_BYTES 128
+typedef struct polr_comm polr_comm;
+int polr_comm_get_unique_id(void *id /* POLR_COMM_ID_BYTES */);
+int polr_comm_create(polr_ctx *ctx, const void *id, int world_size, int rank, polr_comm **out);
+int polr_bcast_build(polr_comm *comm, polr_ht **ht, int root, void *stream);
+int polr_comm_bytes_broadcast(const polr_comm *comm, uint64_t *bytes);
+void polr_comm_destroy(polr_comm *comm);
+
 /* ---------------------------------------------------------------------------------------------
  * Pipeline = what POLARConfig::GenerateJoinOrders produces (src/parallel/polar_config.cpp:19-249):
  * the joins of the run, where each join reads its probe key (a probe-table column, or a build
