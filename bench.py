@@ -245,11 +245,13 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     k = len(wl0["joins"])
 
     # ---- the bank of join orders: the host mirror of POLARConfig::GenerateJoinOrders with the session's enumerator
+    t_enum0 = time.perf_counter()
     gen = phost.generate_join_orders(enumerator, len(names), n_build_cols, cond_left, est,
                                      max_join_orders=max(1, args.max_join_orders), routing=args.routing,
                                      node_info=node_info, return_routing=True)
     if gen is None:
         raise SystemExit("POLAR does not apply to this pipeline (fewer than two join orders)")
+    enumeration_ms = (time.perf_counter() - t_enum0) * 1e3
     paths, routing = gen[0], gen[3]
     if args.pin_path is not None:
         # measurement aid: put join order P of the bank first, so that `--routing default_path` runs the whole table
@@ -407,6 +409,48 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             launches += n_e
             m.enable_timing(False)
 
+    # ---- the reference's harness artefacts (benchmark_runner --log_tuples_routed --measure_pipeline --dir_prefix
+    # --nruns, benchmark/benchmark_runner.cpp:215-355): tmp/<prefix><ts>.csv, -intms.txt, -enumeration.csv per executor
+    # (the reference writes one set per worker thread), tmp/<prefix><ts>-<hash>.csv per run; outside the timed region
+    artefacts = None
+    if args.log_tuples_routed or args.measure_pipeline:
+        from polr_amd import harness
+        P_ = len(paths)
+        cap = (n_chunks // E + 2) * max(P_, 4) + 1024
+        logm = []
+        for e in range(E):
+            m = capi.DeviceMultiplexer(pipe, routing, chunk_size=V, regret_budget=budget,
+                                       init_tuple_count=args.init_tuple_count, atc_multiplier=args.atc_multiplier,
+                                       log_rounds=True, max_log_rounds=cap)
+            if device_scan:
+                m.use_scan_chunks()
+            elif offs is not None:
+                m.set_chunk_offsets(offs)
+            logm.append(m)
+        files, mats, durations = [], [], []
+        prefix = args.dir_prefix + ("r%d-" % rank if world > 1 else "")
+        for _run in range(max(1, args.nruns)):
+            torch.cuda.synchronize()
+            t_r = time.perf_counter()
+            capi.run_resident(logm, ranges, reset=True, finish=True)
+            st_r = capi.finish_many(logm)
+            ms_r = (time.perf_counter() - t_r) * 1e3
+            for e, m in enumerate(logm):
+                _lp, _lt, inter = m.fetch_log()
+                f = harness.write_artefacts(os.getcwd(), prefix, routing, P_, inter, st_r[e]["num_intermediates"], ms_r,
+                                            enumeration_ms, k, "%s rows %d" % (name, n_rows),
+                                            log_tuples_routed=args.log_tuples_routed,
+                                            measure_pipeline=args.measure_pipeline and e == 0)
+                files.append(f)
+                if routing == "alternate" and args.log_tuples_routed:
+                    mats.append(np.asarray(inter, dtype=np.int64).reshape(-1, P_))
+            durations.append(ms_r)
+        artefacts = {"directory": os.path.join(os.getcwd(), "tmp"), "files": len(files) and sum(len(f) for f in files),
+                     "runs": max(1, args.nruns), "median_pipeline_ms": round(float(np.median(durations)), 4)}
+        if mats:
+            artefacts["aggregates"] = {k_: int(sum(v)) for k_, v in harness.aggregates(mats).items()}
+        for m in logm:
+            m.close()
     value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, n_tuples, dt, steps)
     rec = None
     if rank == 0:
@@ -470,6 +514,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             "tuples_per_path": st["input_tuple_count_per_path"],
             "generate_s": round(t_gen, 3), "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
             "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch_info": info,
+            "artefacts": artefacts,
             "timed_region": {"gpu": "routing + probing of every source chunk; probe key columns read from HBM inside the "
                                     "pass" + ("; the pushed-down filter (scan_filter.ms) runs before the clock starts"
                                               if scan_info else "; the query has no probe-side filter"),
@@ -551,6 +596,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true")
+    ap.add_argument("--log-tuples-routed", action="store_true",
+                    help="PRAGMA enable_log_tuples_routed: write tmp/<prefix><ts>.csv, -intms.txt, -enumeration.csv per "
+                         "executor (extra logged passes after the timed region)")
+    ap.add_argument("--measure-pipeline", action="store_true",
+                    help="PRAGMA enable_measure_pipeline: write tmp/<prefix><ts>-<hash>.csv with the pipeline duration in ms")
+    ap.add_argument("--dir-prefix", default="", help="SET dir_prefix: prefix of the artefact file names")
+    ap.add_argument("--nruns", type=int, default=1, help="benchmark_runner --nruns: logged / measured passes")
     ap.add_argument("--pin-path", type=int, default=None, help="measurement aid: make join order P of the bank path 0")
     ap.add_argument("--cpu-sample-rows", type=int, default=8_000_000,
                     help="SSB-skew CPU baseline: rows of each of the two contiguous lineorder samples")

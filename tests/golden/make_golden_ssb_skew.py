@@ -29,6 +29,7 @@ from polr_amd import ssb_skew  # noqa: E402
 from oracle import ref_run  # noqa: E402
 import common  # noqa: E402
 
+RAW = {}
 SHAPE = dict(n_lo=300_000, n_c=30_000, n_s=20_000, n_p=40_000)
 ROUTINGS = ["init_once", "opportunistic", "adaptive_reinit", "dynamic", "exponential_backoff", "default_path"]
 CASES = [("q4.1", 3), ("q4.1", 8), ("q4.2", 3), ("q4.3", 3), ("q3.1", 3), ("q2.1", 8)]
@@ -52,6 +53,11 @@ def run(ref, settings):
         counts = [int(l.split(":")[1]) for l in proc.stdout.splitlines()
                   if ":" in l and l.split(":")[0].strip().isdigit()]
         answer = int(open(os.path.join(workdir, "out", "q.csv")).read().strip().splitlines()[1])
+        enum = glob.glob(os.path.join(workdir, "out", "tmp", "*-enumeration.csv"))
+        RAW.clear()
+        RAW.update({"log": open(logs[0]).read() if logs else None, "intms": open(intms[0]).read() if intms else None,
+                    "enumeration_header": open(enum[0]).read().splitlines()[0] if enum else None,
+                    "names": sorted(os.path.basename(f) for f in glob.glob(os.path.join(workdir, "out", "tmp", "*")))})
         return (open(logs[0]).read() if logs else None), (int(open(intms[0]).read().strip()) if intms else None), \
             counts, answer
     finally:
@@ -80,6 +86,17 @@ def main():
             case["paths"] = None  # POLAR did not engage
             gold["cases"]["%s/%d" % (query, mjo)] = case
             continue
+        if (query, mjo) == ("q4.1", 3):
+            # the reference's files as it wrote them (data fixtures for the harness test): text of the ALTERNATE log,
+            # of the totals file, header of the enumeration file, and the file names of the run
+            raw = {"alternate_log": RAW["log"], "alternate_intms": RAW["intms"],
+                   "enumeration_header": RAW["enumeration_header"], "file_names": RAW["names"]}
+            ll, _i, _c, _a = run(ref, base + ["SET multiplexer_routing TO 'adaptive_reinit'",
+                                              "PRAGMA enable_measure_pipeline"])
+            raw["adaptive_log"] = RAW["log"]
+            raw["adaptive_intms"] = RAW["intms"]
+            raw["adaptive_file_names"] = RAW["names"]
+            gold["raw_files"] = raw
         want = np.asarray(parse_alt(log), dtype=np.uint64)
         case["alternate"] = {"matrix": want.tolist(), "intms": intms}
         pcols, pvalid, ojoins = common.oracle_joins(wl)
