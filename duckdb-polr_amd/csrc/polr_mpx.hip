@@ -669,6 +669,19 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		// finish a lone small round soonest, but a unit costs its wave the same chain of dependent round trips whatever
 		// its size, and with hundreds of executors exploring that wave time is what the pool runs out of (measured on
 		// the SF100 run: 2.29 ms with 64-tuple units, 1.77 ms with 512)
+		{
+			// the fewest probe waves any ring has; the lottery divides them into at most 8 classes
+			const uint32_t min_waves = (n_workers / n_rings) * wpb;
+			uint32_t lot = 1;
+			while (lot * 2 <= std::min<uint32_t>(8, min_waves)) {
+				lot *= 2;
+			}
+			static const long lot_env = [] {
+				const char *v = getenv("POLR_POOL_HI_LOTTERY");
+				return v ? atol(v) : 0l;
+			}();
+			hr->hi_lottery = (lot_env >= 1 && (lot_env & (lot_env - 1)) == 0 && (uint32_t)lot_env <= lot) ? (uint32_t)lot_env : lot;
+		}
 		hr->hi_unit = hu_env >= 64 && hu_env <= 1024 && hu_env % 64 == 0 ? (uint32_t)hu_env : (flat ? 512u : 256u);
 	}
 	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {

@@ -40,6 +40,8 @@ __device__ __forceinline__ void pool_load_run(const PoolRun *run, PoolRun &rh) {
 	rh.n_rings = uni(run->n_rings);
 	rh.units_x = uni(run->units_x);
 	rh.hi_unit = uni(run->hi_unit);
+	rh.hi_lottery = uni(run->hi_lottery);
+	rh.pad = 0;
 	rh.routers_done = 0;
 	rh.abort = 0;
 	rh.host_words = nullptr;
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 	uint32_t cur_path = 0xFFFFFFFFu;
 	unsigned long long lo_ticket = ~0ull, mid_ticket = ~0ull;
 	PoolUnit u;
-	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, mid_ticket, u, c.lane)) {
+	const uint32_t wave_in_ring = ((blockIdx.x - rh.n_router_blocks) / rh.n_rings) * (blockDim.x >> 6) + wave_in_block;
+	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, wave_in_ring, rh.hi_lottery, lo_ticket, mid_ticket,
+	                           u, c.lane)) {
 		if (u.path != cur_path) {
 			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)u.path * POLR_KMAX);
 			uint32_t *dst = (uint32_t *)c.desc;
@@ -223,7 +227,9 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 	uint32_t cur_path = 0xFFFFFFFFu;
 	unsigned long long lo_ticket = ~0ull, mid_ticket = ~0ull;
 	PoolUnit u;
-	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, lo_ticket, mid_ticket, u, c.lane)) {
+	const uint32_t wave_in_ring = ((blockIdx.x - rh.n_router_blocks) / rh.n_rings) * (blockDim.x >> 6) + wave_in_block;
+	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, wave_in_ring, rh.hi_lottery, lo_ticket, mid_ticket,
+	                           u, c.lane)) {
 		c.pf_pos = ~0ull; // (a prefetch belongs to one unit of one join order)
 		if (u.path != cur_path) {
 #pragma unroll

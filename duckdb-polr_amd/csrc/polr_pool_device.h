@@ -79,6 +79,10 @@ struct PoolRun {
 	uint32_t hi_tuples;                     // rounds of up to this many tuples go to the hi queues
 	uint32_t units_x;                       // a big round is cut into about units_x * pool_waves / (executors routing) units
 	uint32_t hi_unit;                       // tuples per unit of a small round
+	uint32_t hi_lottery;                    // power of two <= the probe waves of a ring: wave w of a ring tries for hi ticket t
+	                                        // only if w % hi_lottery == t % hi_lottery (bounds the compare-and-swap storm
+	                                        // a published unit sets off among the pollers of its ring)
+	uint32_t pad;
 	uint32_t n_rings;                       // rings in use: a power of two <= min(POLR_POOL_RINGS, probe workgroups), so that
 	                                        // every ring has waves that serve it
 	uint32_t routers_done;                  // device: routers that have finished
@@ -254,11 +258,11 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 // one lane: take a ticket of a non-blocking queue if it has one (compare-and-swap on its head while head < tail) and
 // read its entry (being written by the router that reserved it)
 __device__ __forceinline__ bool polr_pool_try_claim(unsigned long long *head, unsigned long long *tail, PoolEntry *entries,
-                                                    uint32_t cap, unsigned long long &g0, unsigned long long &g1,
-                                                    uint32_t &tag) {
+                                                    uint32_t cap, uint32_t wave_in_ring, uint32_t lottery,
+                                                    unsigned long long &g0, unsigned long long &g1, uint32_t &tag) {
 	const unsigned long long hh = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const unsigned long long ht = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	if (hh >= ht) {
+	if (hh >= ht || (((uint32_t)hh ^ wave_in_ring) & (lottery - 1u)) != 0) {
 		return false;
 	}
 	unsigned long long expect = hh;
@@ -284,8 +288,9 @@ __device__ __forceinline__ bool polr_pool_try_claim(unsigned long long *head, un
 // (~0ull: none) -- kept across calls, because a wave that holds a not-yet-written lo ticket serves hi units meanwhile.
 // Returns false when the wave has to leave (EXIT entry, abort or watchdog).
 __device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run, PoolSync *sync, uint32_t ring, uint32_t lo_cap,
-                                                    uint32_t hi_cap, unsigned long long &lo_ticket,
-                                                    unsigned long long &mid_ticket, PoolUnit &u, uint32_t lane) {
+                                                    uint32_t hi_cap, uint32_t wave_in_ring, uint32_t lottery,
+                                                    unsigned long long &lo_ticket, unsigned long long &mid_ticket,
+                                                    PoolUnit &u, uint32_t lane) {
 	PoolRingCtl *ctl = &sync->ctl[ring];
 	uint32_t spins = 0;
 	while (true) {
@@ -293,7 +298,8 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run, PoolSync *sync
 		uint32_t tag = 0, got = 0;
 		if (lane == 0) {
 			// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
-			got = polr_pool_try_claim(&ctl->hi_head, &ctl->hi_tail, polr_pool_hi(sync, ring, lo_cap, hi_cap), hi_cap, g0, g1, tag)
+			got = polr_pool_try_claim(&ctl->hi_head, &ctl->hi_tail, polr_pool_hi(sync, ring, lo_cap, hi_cap), hi_cap,
+			                          wave_in_ring, lottery, g0, g1, tag)
 			          ? 1u
 			          : 0u;
 			if (!got) {

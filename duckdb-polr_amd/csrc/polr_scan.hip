@@ -305,6 +305,12 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
+	if (p->scan_valid) {
+		// A re-scan rewrites the selection, the chunk boundaries and the device copies of the pipeline in place, and runs
+		// of the previous scan may still be in flight on their multiplexers' streams (passes are enqueued without a
+		// host synchronisation): settle the device first.  (The first scan of a pipeline has nothing to wait for.)
+		HIPCHK(ctx, hipDeviceSynchronize());
+	}
 	const uint64_t n_rows = p->n_probe_rows;
 	const uint64_t n_vec = (n_rows + vector_size - 1) / vector_size;
 	const uint64_t n_blocks = (n_vec + 1023) / 1024;
