@@ -560,13 +560,192 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     return rec
 
 
+def run_job_full(args, env, steps, warmup, with_cpu):
+    """BASELINE.json configs[3]: the 113 JOB-shaped pipelines (polr_amd/job_family.py), whole queries dealt round-robin
+    to the ranks, nothing exchanged.  One step = one pass of EVERY pipeline of the rank (one pool launch each,
+    enqueued back to back)."""
+    torch, dist, dev, ctx, world, rank = env["torch"], env["dist"], env["dev"], env["ctx"], env["world"], env["rank"]
+    from polr_amd import capi, job_family as jf
+    from polr_amd import dist as pdist
+    from polr_amd import host as phost
+    V = args.chunk_size
+    scale = args.scale if args.scale is not None else 1.0
+    t_gen0 = time.time()
+    shapes = jf.shapes()
+    names_all = sorted(shapes)
+    mine = [names_all[i] for i in pdist.shard_queries(len(names_all), world, rank)]
+    if os.environ.get("POLR_JOB_LIMIT"):
+        mine = mine[:int(os.environ["POLR_JOB_LIMIT"])]
+    tables = jf.Tables(scale=scale)
+    dev_cols = {}
+
+    def dev_col(table, cname, arr):
+        key = (table, cname)
+        if key not in dev_cols:
+            dev_cols[key] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        return dev_cols[key]
+
+    E = args.executors if args.executors > 0 else 8
+    cases = []
+    for name in mine:
+        wl = jf.workload(name, tables, shapes[name])
+        if wl is None:
+            continue
+        k = len(wl["joins"])
+        pn = list(wl["probe"]["cols"].keys())
+        gen = phost.generate_join_orders("each_last_once", len(pn), [len(j["payload"]) for j in wl["joins"]],
+                                         wl["cond_left_index"], [len(j["keys"][0]) for j in wl["joins"]],
+                                         max_join_orders=8, routing=args.routing)
+        if gen is None:
+            continue
+        paths = gen[0]
+        joins = capi.build_joins(ctx, wl, auto=not args.reference_tables)
+        tens = [dev_col(wl["probe"]["name"], c, wl["probe"]["cols"][c]) for c in pn]
+        n_rows = len(wl["probe"]["cols"][pn[0]])
+        cols = [capi.dev_col(t.data_ptr(), t.element_size(), signed=True) for t in tens]
+        pipe = capi.Pipeline(ctx, cols, n_rows, joins, paths)
+        flt = wl["probe"].get("filter")
+        if flt:
+            n_tuples, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt], vector_size=V)
+        else:
+            n_tuples, n_chunks = n_rows, (n_rows + V - 1) // V
+        e_n = max(1, min(E, n_chunks))
+        mpxs = []
+        for e in range(e_n):
+            m = capi.DeviceMultiplexer(pipe, args.routing, chunk_size=V, regret_budget=args.regret_budget,
+                                       init_tuple_count=args.init_tuple_count, atc_multiplier=args.atc_multiplier,
+                                       log_rounds=False)
+            if flt:
+                m.use_scan_chunks()
+            mpxs.append(m)
+        ranges = [((e * n_chunks) // e_n, ((e + 1) * n_chunks) // e_n) for e in range(e_n)]
+        ji = [{"key_bytes": 4, "n_rows": len(j["keys"][0]), "perfect": joins[x][0].info()["kind"] == 1}
+              for x, j in enumerate(wl["joins"])]
+        cases.append({"name": name, "wl": wl, "pipe": pipe, "joins": joins, "mpxs": mpxs, "ranges": ranges,
+                      "n_tuples": int(n_tuples), "paths": paths, "k": k, "ji": ji})
+        if rank == 0 and len(cases) % 10 == 0:
+            print("job_full: %d pipelines set up, %.1f s" % (len(cases), time.time() - t_gen0), file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen0
+    stats = {}
+
+    def step(fetch):
+        for c in cases:
+            capi.run_resident(c["mpxs"], c["ranges"], reset=True, finish=True)
+        if fetch:
+            for c in cases:
+                stats[c["name"]] = capi.finish_many(c["mpxs"])
+
+    for _ in range(warmup):
+        t_w = time.time()
+        step(True)
+        if rank == 0:
+            print("job_full: warm-up pass %.3f s" % (time.time() - t_w), file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i == steps - 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    kernel_ms, launches = 0.0, 0
+    if not args.no_kernel_events:
+        for c in cases:
+            for m in c["mpxs"]:
+                m.kernel_time()
+                m.enable_timing(True)
+        for i in range(steps):
+            step(i == steps - 1)
+        torch.cuda.synchronize()
+        for c in cases:
+            for m in c["mpxs"]:
+                ms_e, n_e = m.kernel_time()
+                kernel_ms += ms_e
+                launches += n_e
+                m.enable_timing(False)
+    my_tuples = sum(c["n_tuples"] for c in cases)
+    value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, my_tuples, dt, steps)
+    alg, inter, rounds, count = 0.0, 0, 0, 0
+    for c in cases:
+        P, k = len(c["paths"]), c["k"]
+        tpp = [sum(st["input_tuple_count_per_path"][p] for st in stats[c["name"]]) for p in range(P)]
+        so = [[sum(st["stage_out"][p][j] for st in stats[c["name"]]) for j in range(k)] for p in range(P)]
+        alg += algorithmic_bytes(c["ji"], c["paths"].tolist(), tpp, so)
+        inter += sum(st["num_intermediates"] for st in stats[c["name"]])
+        rounds += sum(st["num_rounds"] for st in stats[c["name"]])
+        count += sum(so[p][k - 1] for p in range(P))
+    rec = None
+    if rank == 0:
+        roof = None
+        if launches:
+            sec = kernel_ms / 1e3 / steps
+            roof = {"bound": "hbm", "achieved": round(alg / sec / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "polr_pool_kernel / polr_pool_flat_kernel (one launch per pipeline and pass)",
+                    "algorithmic_bytes_per_step": round(alg), "kernel_ms_per_step": round(kernel_ms / steps, 4),
+                    "launches_per_step": launches / steps,
+                    "note": "rank 0's pipelines; algorithmic bytes per SURVEY.md 8(d) summed over them"}
+        cpu = None
+        if with_cpu:
+            try:
+                from oracle import polr_oracle as orc
+                done, secs = 0, 0.0
+                for c in cases[:4]:
+                    wl = c["wl"]
+                    oj = [orc.JoinSpec(orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"])
+                          for j in wl["joins"]]
+                    sel = wl["probe"].get("filter_sel")
+                    pc = list(wl["probe"]["cols"].values())
+                    cap = 300_000
+                    if sel is not None:
+                        sel = sel[:cap]
+                        n_s = len(sel)
+                    else:
+                        pc = [a[:cap] for a in pc]
+                        n_s = len(pc[0])
+                    t_c = time.time()
+                    orc.run_pipeline(pc, oj, c["paths"], routing=args.routing, collect_output=False, sel=sel)
+                    secs += time.time() - t_c
+                    done += n_s
+                cpu = {"value": round(done / secs, 1), "unit": "probe-tuples/s", "cores": 1, "kind": "port",
+                       "sample": "the first %d probe tuples of the first %d pipelines of rank 0 through the oracle "
+                                 "restatement, single thread (the reference cannot run the synthetic JOB-shaped family: "
+                                 "its queries exist as shapes only)" % (cap, min(4, len(cases)))}
+            except Exception as e:
+                cpu = {"value": None, "error": str(e)[:300]}
+        rec = {"metric": "probe-tuples/s", "value": round(value, 1), "unit": "tuples/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": round(dt_max / steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "job_full: the 113 JOB-shaped pipelines (IMDB cardinalities x%.3g), %d of them on "
+                                      "this rank, %d probe tuples per pass on this rank; whole queries round-robin over "
+                                      "the GPUs, no exchange" % (scale, len(cases), my_tuples),
+                          "routing": args.routing, "join_enumerator": "each_last_once", "max_join_orders": 8,
+                          "executors_per_pipeline": E, "chunk_size": V, "sink": "count(*)",
+                          "joins_per_pipeline": sorted(set(c["k"] for c in cases))},
+               "total_intermediates": int(inter), "routing_rounds": int(rounds), "count_star_sum": int(count),
+               "pipelines": len(cases), "generate_s": round(t_gen, 3), "roofline": roof, "cpu_baseline": cpu}
+        if cpu and cpu.get("value"):
+            rec["gpu_over_cpu"] = round(value / cpu["value"], 2)
+    for c in cases:
+        for m in c["mpxs"]:
+            m.close()
+        c["pipe"].close()
+        for ht, _ in c["joins"]:
+            ht.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ssb_skew_q41",
-                    help="ssb_skew_q41 (default; also _q42 _q43 _q31 _q21), job_q18, job_light_01")
+                    help="ssb_skew_q41 (default; also _q42 _q43 _q31 _q21), job_q18, job_light_01, job_full (the 113 "
+                         "JOB-shaped pipelines, BASELINE configs[3])")
     ap.add_argument("--scale", type=float, default=None,
                     help="SSB-skew: scale factor per GPU (default 100; with --strong: of the whole job); JOB shapes: "
                          "fraction of the IMDB cardinalities (default 1)")
@@ -633,6 +812,15 @@ def main():
     from polr_amd import capi
     ctx = capi.Context(local_rank)  # raises without the HIP library / a gfx950 device: no fallback
     env = {"torch": torch, "dist": dist, "dev": dev, "ctx": ctx, "world": world, "rank": rank}
+    if args.workload == "job_full":
+        head = run_job_full(args, env, args.steps, args.warmup, with_cpu=world == 1 and not args.no_cpu_baseline)
+        if rank == 0:
+            print(json.dumps(head))
+        ctx.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     is_ssb = args.workload in SSB_QUERIES
     scale = args.scale if args.scale is not None else (100.0 if is_ssb else 1.0)
     head = run_case(args.workload, scale, args, env, args.steps, args.warmup, with_cpu=world == 1 and not args.no_cpu_baseline)

@@ -1,0 +1,88 @@
+"""BASELINE.json configs[3] -- the 113 JOB-shaped pipelines (polr_amd/job_family.py): every query of
+benchmark/imdb_plan_cost/queries yields a multiplexed pipeline; sampled ones run on the device (-m gpu) against the
+oracle: ALTERNATE matrix over the enumerated join orders, an adaptive trace and COUNT(*)."""
+import numpy as np
+import pytest
+
+import common
+from common import orc
+from polr_amd import host as phost
+from polr_amd import job_family as jf
+
+SHAPES = jf.shapes()
+SAMPLE = ["01a", "06d", "10c", "13b", "16b", "18a", "22c", "25a", "29a", "33c"]
+
+
+def test_all_113_queries_give_a_pipeline():
+    t = jf.Tables(scale=0.002)
+    assert len(SHAPES) == 113
+    n_dep = 0
+    for name in sorted(SHAPES):
+        wl = jf.workload(name, t, SHAPES[name])
+        assert wl is not None and 2 <= len(wl["joins"]) <= 8, name
+        for x, j in enumerate(wl["joins"]):
+            sj, sc = j["key_src"][0]
+            assert sj < x  # a join is keyed by the probe side or by an EARLIER join's build column
+            n_dep += sj >= 0
+        # the host mirror of POLARConfig::GenerateJoinOrders accepts it and respects the dependencies
+        gen = phost.generate_join_orders("each_last_once", len(wl["probe"]["cols"]),
+                                         [len(j["payload"]) for j in wl["joins"]], wl["cond_left_index"],
+                                         [len(j["keys"][0]) for j in wl["joins"]], max_join_orders=8)
+        assert gen is not None and gen[0][0].tolist() == list(range(len(wl["joins"]))), name
+    assert n_dep > 100
+
+
+def test_generation_is_deterministic():
+    a = jf.workload("18a", jf.Tables(scale=0.002), SHAPES["18a"])
+    b = jf.workload("18a", jf.Tables(scale=0.002), SHAPES["18a"])
+    assert all(np.array_equal(x["keys"][0], y["keys"][0]) for x, y in zip(a["joins"], b["joins"]))
+    assert all(np.array_equal(a["probe"]["cols"][c], b["probe"]["cols"][c]) for c in a["probe"]["cols"])
+
+
+def _oracle(wl, paths, routing):
+    oj = [orc.JoinSpec(orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"]) for j in wl["joins"]]
+    sel = wl["probe"].get("filter_sel")
+    offs = None
+    if sel is not None:
+        import bench
+        offs = bench.chunk_offsets_for(sel, len(next(iter(wl["probe"]["cols"].values()))), 1024)
+    return orc.run_pipeline(list(wl["probe"]["cols"].values()), oj, paths, routing=routing, caching=False,
+                            collect_output=False, sel=sel, chunk_offsets=offs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SAMPLE)
+def test_device_matches_oracle(gpu_ctx, name):
+    from polr_amd import capi
+    t = jf.Tables(scale=0.004)
+    wl = jf.workload(name, t, SHAPES[name])
+    pn = list(wl["probe"]["cols"].keys())
+    paths = phost.generate_join_orders("each_last_once", len(pn), [len(j["payload"]) for j in wl["joins"]],
+                                       wl["cond_left_index"], [len(j["keys"][0]) for j in wl["joins"]],
+                                       max_join_orders=8)[0]
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, paths)
+    flt = wl["probe"].get("filter")
+    if flt:
+        n_sel, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt])
+        assert n_sel == len(wl["probe"]["filter_sel"])
+    else:
+        n_chunks = (len(cols[0]) + 1023) // 1024
+    k, P = len(wl["joins"]), len(paths)
+    for routing in ("alternate", "adaptive_reinit"):
+        ref = _oracle(wl, paths, routing)
+        mpx = capi.DeviceMultiplexer(pipe, routing, max_log_rounds=1 << 16)
+        if flt:
+            mpx.use_scan_chunks()
+        capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+        st = mpx.finish()
+        _, _, inter = mpx.fetch_log()
+        if routing == "alternate":
+            assert np.array_equal(inter.reshape(-1, P), ref["alt_matrix"]), name
+        else:
+            assert list(inter) == list(ref["intermediates_per_round"]), name
+            assert sum(st["stage_out"][p][k - 1] for p in range(P)) == ref["num_output_rows"]
+        assert st["num_intermediates"] == ref["num_intermediates"]
+        mpx.close()
+    pipe.close()
