@@ -57,6 +57,7 @@ struct polr_mpx {
 	ResidentSync *sync_dev = nullptr;  // arrival counters of this executor
 	char *execs_dev = nullptr;         // run header + executor descriptors + morsel cursor (owned by the first multiplexer of a run)
 	uint32_t execs_cap = 0;
+	std::vector<char> execs_host;      // what execs_dev holds (a pass that repeats the last one re-sends nothing)
 	PoolSync *pool_dev = nullptr;      // unit rings of the runs this multiplexer leads
 	uint32_t pool_lo_cap = 0, pool_hi_cap = 0;
 	bool pool_dirty = false;           // a run was given up: rings and tickets are re-initialised before the next one
@@ -611,6 +612,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		const uint32_t cap = std::max<uint32_t>(n, 8);
 		HIPCHK(ctx, hipMalloc((void **)&m0->execs_dev, POOL_HEADER_BYTES + (size_t)cap * sizeof(ResidentExec) + 64));
 		m0->execs_cap = cap;
+		m0->execs_host.clear();
 	}
 	// unit rings: sized for everything the executors of this run can have in flight (two slots each) plus the EXIT
 	// entries, with a factor of two to spare
@@ -703,7 +705,6 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hr->host_words = nullptr;
 	for (uint32_t i = 0; i < n; i++) {
 		polr_mpx *m = ms[i];
-		m->res_epoch = (m->res_epoch + 1) & 0xFFFu;
 		ex[i].mpx = m->dev;
 		ex[i].sync = m->sync_dev;
 		ex[i].counts = m->counts_dev;
@@ -716,7 +717,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ex[i].chunk_offsets = m->chunk_offsets_dev;
 		ex[i].n_chunks = m->n_chunks;
 		ex[i].n_tuples = p->n_tuples;
-		ex[i].epoch = m->res_epoch;
+		ex[i].epoch = 0; // (the pool protocol has no epochs: tickets are monotonic across runs)
 		ex[i].flags = flags;
 		ex[i].registered = 0;
 		ex[i].pad = 0;
@@ -725,9 +726,17 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ex[i].stamps = nullptr;
 		((volatile uint32_t *)m->done_host)[1] = 0;
 	}
-	// (pageable source: staged by the runtime before the call returns)
-	HIPCHK(ctx, hipMemcpyAsync(m0->execs_dev, host.data(), POOL_HEADER_BYTES + (size_t)n * sizeof(ResidentExec),
-	                           hipMemcpyHostToDevice, st));
+	// A pass that repeats the previous one (same executors, ranges, flags: every step of a measurement loop) finds its
+	// descriptors on the device already; only the two words the device writes (routers_done, abort) are cleared.
+	// Otherwise: one copy (pageable source: staged by the runtime before the call returns).
+	const size_t used = POOL_HEADER_BYTES + (size_t)n * sizeof(ResidentExec);
+	if (m0->execs_host.size() == used && memcmp(m0->execs_host.data(), host.data(), used) == 0) {
+		static_assert(offsetof(PoolRun, abort) == offsetof(PoolRun, routers_done) + 4, "cleared together");
+		HIPCHK(ctx, hipMemsetAsync(m0->execs_dev + offsetof(PoolRun, routers_done), 0, 8, st));
+	} else {
+		HIPCHK(ctx, hipMemcpyAsync(m0->execs_dev, host.data(), used, hipMemcpyHostToDevice, st));
+		m0->execs_host.assign(host.begin(), host.begin() + used);
+	}
 	if (morsel_chunks) {
 		const unsigned long long first = morsel_begin;
 		HIPCHK(ctx, hipMemcpyAsync(cursor_dev, &first, 8, hipMemcpyHostToDevice, st));
