@@ -296,25 +296,30 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     cols = [capi.dev_col(t.data_ptr(), t.element_size(), signed=s) for t, s in zip(tens, signed)]
     pipe = capi.Pipeline(ctx, cols, n_rows, joins, paths)
     scan_info = None
-    device_scan = bool(flt) and not args.host_filter
+    lip_mask = 0
+    if args.enable_lip:
+        for x, j in enumerate(wl0["joins"]):
+            if len(j["key_src"]) == 1 and j["key_src"][0][0] < 0:
+                lip_mask |= 1 << x
+    device_scan = (bool(flt) or lip_mask != 0) and not args.host_filter
     sel_t = None
     if device_scan:
         # source side on the device: the pushed-down filter of the table scan thins the
         # 1024-row vectors into the chunks the multiplexer sees; selection and chunk boundaries stay in HBM
-        f3 = [(names.index(c), op, const) for c, op, const in flt]
+        f3 = [(names.index(c), op, const) for c, op, const in (flt or [])]
         best = None
         for _ in range(5):
             torch.cuda.synchronize()
             t_s = time.perf_counter()
-            n_tuples, n_chunks = pipe.scan_filter(f3, vector_size=V)
+            n_tuples, n_chunks = pipe.scan_filter(f3, vector_size=V, lip_joins=lip_mask)
             dt_s = time.perf_counter() - t_s
             best = dt_s if best is None else min(best, dt_s)
-        scan_bytes = 2 * sum(tens[names.index(c)].element_size() for c, _, _ in flt) * n_rows + 4 * n_tuples
+        scan_bytes = 2 * sum(tens[names.index(c)].element_size() for c, _, _ in (flt or [])) * n_rows + 4 * n_tuples
         scan_info = {"rows": n_rows, "selected": int(n_tuples), "chunks": int(n_chunks),
                      "ms": round(best * 1e3, 4), "algorithmic_bytes": int(scan_bytes),
                      "GB/s": round(scan_bytes / best / 1e9, 1),
                      "note": "whole call (five kernels, one synchronisation); outside the timed region"}
-        if sel is not None and n_tuples != len(sel):
+        if sel is not None and not lip_mask and n_tuples != len(sel):
             raise SystemExit("device scan selected %d rows, the workload's host filter %d" % (n_tuples, len(sel)))
         offs = None
     else:
@@ -504,6 +509,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                        "max_join_orders": args.max_join_orders, "join_orders": paths.tolist(), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
                        "sink": "count(*)", "probe_partition_per_gpu": int(n_tuples), "executors_per_gpu": E,
+                       "lip_joins": [wl0["joins"][x]["name"] for x in range(k) if (lip_mask >> x) & 1],
                        "launch": "pool (one launch per pass: %d router waves + shared probe waves)" % E,
                        "chunks_per_executor": ("morsels of %d" % args.morsels) if args.morsels > 0 else "fixed ranges",
                        "build_tables": ["perfect" if ji["perfect"] else "hash" for ji in joins_info],
@@ -775,6 +781,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true")
+    ap.add_argument("--enable-lip", action="store_true",
+                    help="PRAGMA enable_lip: the filters of the joins keyed by a source column thin the source chunks before "
+                         "the multiplexer sees them (polr_pipeline_scan_filter_lip)")
     ap.add_argument("--log-tuples-routed", action="store_true",
                     help="PRAGMA enable_log_tuples_routed: write tmp/<prefix><ts>.csv, -intms.txt, -enumeration.csv per "
                          "executor (extra logged passes after the timed region)")

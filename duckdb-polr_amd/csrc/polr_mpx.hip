@@ -524,7 +524,7 @@ static_assert(sizeof(PoolRun) <= POOL_HEADER_BYTES, "run header");
 
 static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                              uint32_t n, polr_out *out, uint32_t flags, uint64_t morsel_begin, uint64_t morsel_end,
-                             uint32_t morsel_chunks) {
+                             uint32_t morsel_chunks, bool backpressure = false) {
 	if (!ms || n == 0 || !ms[0] || (morsel_chunks == 0 && (!chunk_begin || !chunk_end))) {
 		return POLR_E_INVALID;
 	}
@@ -713,7 +713,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ex[i].morsel_cursor = morsel_chunks ? cursor_dev : nullptr;
 		ex[i].morsel_end = morsel_end;
 		ex[i].morsel_chunks = morsel_chunks;
-		ex[i].pad2 = 0;
+		ex[i].path_plus1 = backpressure ? i + 1 : 0;
 		ex[i].chunk_offsets = m->chunk_offsets_dev;
 		ex[i].n_chunks = m->n_chunks;
 		ex[i].n_tuples = p->n_tuples;
@@ -790,6 +790,29 @@ int polr_mpx_run_resident_morsels(polr_mpx **ms, void *stream, uint64_t chunk_be
 		return POLR_E_INVALID;
 	}
 	return run_resident_impl(ms, stream, nullptr, nullptr, n, out, flags, chunk_begin, chunk_end, morsel_chunks);
+}
+
+// BACKPRESSURE routing (MultiplexerRouting::BACKPRESSURE): one executor per join order, all pulling morsels from one
+// cursor -- the join orders race for the source (src/parallel/pipeline.cpp:147-156: one PipelineTask per join order
+// over ONE shared source state; polar_config.cpp:128-147).  Executor i runs join order i.
+int polr_mpx_run_backpressure(polr_mpx **ms, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
+                              uint32_t morsel_chunks, polr_out *out, uint32_t flags) {
+	POLR_ENTRY();
+	if (!ms || !ms[0] || morsel_chunks == 0) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = ms[0]->pipe;
+	polr_ctx *ctx = p->ctx;
+	const uint32_t n = p->n_paths;
+	for (uint32_t i = 0; i < n; i++) {
+		if (!ms[i] || ms[i]->pipe != p) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "BACKPRESSURE needs one multiplexer per join order (%u) of the same pipeline", n);
+		}
+		if (ms[i]->cfg.routing != POLR_ROUTE_BACKPRESSURE && ms[i]->cfg.routing != POLR_ROUTE_DEFAULT_PATH) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "multiplexer %u does not route BACKPRESSURE / DEFAULT_PATH", i);
+		}
+	}
+	return run_resident_impl(ms, stream, nullptr, nullptr, n, out, flags, chunk_begin, chunk_end, morsel_chunks, true);
 }
 
 int polr_mpx_reset(polr_mpx *m, void *stream) {

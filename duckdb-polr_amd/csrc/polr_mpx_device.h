@@ -334,7 +334,8 @@ struct ResidentExec {
 	// the parallel scan state; chunk_begin / chunk_end are ignored
 	unsigned long long *morsel_cursor;
 	uint64_t morsel_end;
-	uint32_t morsel_chunks, pad2;
+	uint32_t morsel_chunks;
+	uint32_t path_plus1; // BACKPRESSURE: this executor sends everything down join order path_plus1 - 1 (0: as routed)
 	unsigned long long *stamps; // diagnostic builds only (POLR_DIAG_STAMPS), else nullptr
 };
 

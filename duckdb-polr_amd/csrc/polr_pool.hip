@@ -65,7 +65,7 @@ __device__ __forceinline__ void pool_load_exec(const ResidentExec *xp, ResidentE
 	x.morsel_cursor = (unsigned long long *)uni64((uint64_t)xp->morsel_cursor);
 	x.morsel_end = uni64(xp->morsel_end);
 	x.morsel_chunks = uni(xp->morsel_chunks);
-	x.pad2 = 0;
+	x.path_plus1 = uni(xp->path_plus1);
 }
 
 // the router waves of a router workgroup; router_dwords: LDS dwords per router wave

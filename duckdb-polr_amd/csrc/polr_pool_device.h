@@ -514,6 +514,12 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			}
 			if (lane == 0) {
 				polr_router_route(m, round, prefix, us, rh.pool_waves, &oc);
+				if (x.path_plus1) {
+					// BACKPRESSURE (src/parallel/pipeline.cpp:147-156, polar_config.cpp:128-147): this executor IS one
+					// join order; its multiplexer routes DEFAULT_PATH, the order it stands for replaces path 0
+					round->path = x.path_plus1 - 1u;
+					m->last_path = x.path_plus1 - 1u;
+				}
 			}
 			__builtin_amdgcn_wave_barrier();
 			const bool done = ((volatile DevMpx *)m)->done != 0;

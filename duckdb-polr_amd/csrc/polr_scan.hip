@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "polr_internal.h"
@@ -40,10 +41,109 @@ struct DevFilterSet {
 	uint32_t pad;
 };
 
+// LIP (lookahead information passing, the reference's `PRAGMA enable_lip`): the filters of the joins further up the
+// pipeline are applied to the source chunks before they enter it (PipelineExecutor::FetchFromSource,
+// src/parallel/pipeline_executor.cpp:396-465 -> PhysicalHashJoin::ProbeBloomFilter, physical_hash_join.cpp:579-635).
+// The reference probes a bloom filter per eligible join (single condition, key traced back to a source column, filtered
+// build side: physical_join.cpp:57-107) in an order it re-sorts by miss rate every 64 chunks; the order changes the
+// work, never the survivors.  Here the "filter" of a join is its own index -- bit table, unique-key or run hash table:
+// a bloom filter without false positives -- evaluated for the rows that pass the table filters, cheapest first.
+struct DevLip {
+	const uint8_t *key_data;
+	const uint8_t *key_valid;
+	const void *table;
+	uint64_t mask;
+	int64_t min_value;
+	uint64_t range;
+	uint32_t key_width, key_signed, kind, pad;
+};
+struct DevLipSet {
+	DevLip f[POLR_KMAX];
+	uint32_t n;
+	uint32_t pad;
+};
+
+__device__ __forceinline__ bool lip_contains(const DevLip &f, uint64_t row) {
+	if (f.key_valid && !f.key_valid[row]) {
+		return false; // NULL never joins
+	}
+	const uint8_t *p = f.key_data + row * f.key_width;
+	uint64_t key;
+	switch (f.key_width) {
+	case 1:
+		key = f.key_signed && f.kind == KIND_PERFECT ? (uint64_t)(int64_t)*(const int8_t *)p : (uint64_t)*p;
+		break;
+	case 2:
+		key = f.key_signed && f.kind == KIND_PERFECT ? (uint64_t)(int64_t)*(const int16_t *)p : (uint64_t)*(const uint16_t *)p;
+		break;
+	case 4:
+		key = f.key_signed && f.kind == KIND_PERFECT ? (uint64_t)(int64_t)*(const int32_t *)p : (uint64_t)*(const uint32_t *)p;
+		break;
+	default:
+		key = *(const uint64_t *)p;
+		break;
+	}
+	if (f.kind == KIND_PERFECT) {
+		uint64_t idx;
+		bool in_range;
+		if (f.key_signed) {
+			const int64_t v = (int64_t)key;
+			in_range = v >= f.min_value && (uint64_t)(v - f.min_value) <= f.range;
+			idx = (uint64_t)(v - f.min_value);
+		} else {
+			in_range = key >= (uint64_t)f.min_value && key - (uint64_t)f.min_value <= f.range;
+			idx = key - (uint64_t)f.min_value;
+		}
+		return in_range && ((((const uint32_t *)f.table)[idx >> 5] >> (idx & 31)) & 1u);
+	}
+	if (f.kind == KIND_S8) {
+		const uint2 *tab = (const uint2 *)f.table; // {key32, row}
+		const uint32_t k32 = (uint32_t)key;
+		uint64_t h = polr_murmurhash64((uint64_t)k32) & f.mask;
+		while (true) {
+			const uint2 e = tab[h];
+			if (e.y == S8_EMPTY_ROW) {
+				return false;
+			}
+			if (e.x == k32) {
+				return true;
+			}
+			h = (h + 1) & f.mask;
+		}
+	}
+	// KIND_S16: {key64, start, count}
+	if (key == S16_EMPTY_KEY) {
+		return true; // (the sentinel key has a side entry: let the join decide)
+	}
+	const uint4 *tab = (const uint4 *)f.table;
+	uint64_t h = polr_murmurhash64(key) & f.mask;
+	while (true) {
+		const uint4 e = tab[h];
+		const uint64_t k = ((uint64_t)e.y << 32) | e.x;
+		if (k == S16_EMPTY_KEY) {
+			return false;
+		}
+		if (k == key) {
+			return e.w != 0;
+		}
+		h = (h + 1) & f.mask;
+	}
+}
+
 #define PACK_SHIFT 40 // low 40 bits: tuples, high 24: non-empty vectors
 #define PACK_MASK ((1ull << PACK_SHIFT) - 1)
 
-__device__ __forceinline__ bool row_passes(const DevFilterSet &fs, uint64_t row) {
+__device__ __forceinline__ bool row_passes_filters(const DevFilterSet &fs, uint64_t row);
+
+__device__ __forceinline__ bool row_passes(const DevFilterSet &fs, const DevLipSet &lip, uint64_t row) {
+	bool ok = row_passes_filters(fs, row);
+	for (uint32_t i = 0; i < lip.n; i++) {
+		ok = ok && lip_contains(lip.f[i], row);
+	}
+	return ok;
+}
+
+__device__ __forceinline__ bool row_passes_filters(const DevFilterSet &fs, uint64_t row) {
 	bool ok = true;
 	for (uint32_t i = 0; i < fs.n; i++) {
 		const DevFilter &f = fs.f[i];
@@ -111,7 +211,7 @@ __device__ __forceinline__ bool row_passes(const DevFilterSet &fs, uint64_t row)
 }
 
 // one wave per vector (grid-stride); counts[v] = survivors of vector v, packed with its non-empty flag
-__global__ __launch_bounds__(256) void polr_tscan_count_kernel(DevFilterSet fs, uint64_t n_rows, uint32_t V,
+__global__ __launch_bounds__(256) void polr_tscan_count_kernel(DevFilterSet fs, DevLipSet lip, uint64_t n_rows, uint32_t V,
                                                               uint64_t n_vec, unsigned long long *__restrict__ packed) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -122,7 +222,7 @@ __global__ __launch_bounds__(256) void polr_tscan_count_kernel(DevFilterSet fs, 
 		uint32_t cnt = 0;
 		for (uint64_t r0 = begin; r0 < end; r0 += 64) {
 			const uint64_t row = r0 + lane;
-			const bool pass = row < end && row_passes(fs, row);
+			const bool pass = row < end && row_passes(fs, lip, row);
 			cnt += (uint32_t)__popcll(__ballot(pass));
 		}
 		if (lane == 0) {
@@ -224,7 +324,7 @@ __global__ __launch_bounds__(1024) void polr_tscan_apply_kernel(unsigned long lo
 }
 
 // one wave per vector: ascending row ids of the survivors, chunk boundary of every non-empty vector
-__global__ __launch_bounds__(256) void polr_tscan_write_kernel(DevFilterSet fs, uint64_t n_rows, uint32_t V,
+__global__ __launch_bounds__(256) void polr_tscan_write_kernel(DevFilterSet fs, DevLipSet lip, uint64_t n_rows, uint32_t V,
                                                               uint64_t n_vec,
                                                               const unsigned long long *__restrict__ prefix,
                                                               uint32_t *__restrict__ sel,
@@ -250,7 +350,7 @@ __global__ __launch_bounds__(256) void polr_tscan_write_kernel(DevFilterSet fs, 
 		const uint64_t end = begin + V < n_rows ? begin + V : n_rows;
 		for (uint64_t r0 = begin; r0 < end; r0 += 64) {
 			const uint64_t row = r0 + lane;
-			const bool pass = row < end && row_passes(fs, row);
+			const bool pass = row < end && row_passes(fs, lip, row);
 			const uint64_t m = __ballot(pass);
 			if (pass) {
 				const uint32_t rank =
@@ -266,6 +366,11 @@ extern "C" {
 
 int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_filter *filters, uint32_t n_filters,
                               uint32_t vector_size, uint64_t *n_selected, uint64_t *n_chunks) {
+	return polr_pipeline_scan_filter_lip(p, stream, filters, n_filters, 0, vector_size, n_selected, n_chunks);
+}
+
+int polr_pipeline_scan_filter_lip(polr_pipeline *p, void *stream, const polr_scan_filter *filters, uint32_t n_filters,
+                                  uint32_t lip_joins, uint32_t vector_size, uint64_t *n_selected, uint64_t *n_chunks) {
 	POLR_ENTRY();
 	if (!p || (!filters && n_filters)) {
 		return POLR_E_INVALID;
@@ -302,6 +407,40 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 		fs.f[i].is_signed = is_signed ? 1u : 0u;
 		fs.f[i].op = f.op;
 		fs.f[i].constant = f.constant;
+	}
+	// LIP: the joins whose filters are applied at the source, smallest index structure first (cheapest test first)
+	DevLipSet lip;
+	memset(&lip, 0, sizeof(lip));
+	{
+		std::vector<uint32_t> js;
+		for (uint32_t j = 0; j < p->k; j++) {
+			if (!((lip_joins >> j) & 1u)) {
+				continue;
+			}
+			const DevJoin &dj = p->host_count.joins[j];
+			if (dj.n_keys != 1 || dj.key_src_join[0] >= 0) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "LIP: join %u is not keyed by one column of the source (physical_join.cpp:57-107)", j);
+			}
+			js.push_back(j);
+		}
+		if (lip_joins >> p->k) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "LIP: join mask names a join beyond the %u of the pipeline", p->k);
+		}
+		std::sort(js.begin(), js.end(), [&](uint32_t a, uint32_t b) { return p->hts[a]->device_bytes < p->hts[b]->device_bytes; });
+		for (uint32_t j : js) {
+			const DevJoin &dj = p->host_count.joins[j];
+			const OwnedCol &c = p->probe_cols[dj.key_src_col[0]];
+			DevLip &f = lip.f[lip.n++];
+			f.key_data = c.data;
+			f.key_valid = c.valid;
+			f.key_width = c.width;
+			f.key_signed = dj.key_signed;
+			f.kind = dj.kind;
+			f.table = dj.table;
+			f.mask = dj.mask;
+			f.min_value = dj.min_value;
+			f.range = dj.range;
+		}
 	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
@@ -359,11 +498,11 @@ int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_fi
 		const uint32_t waves_per_block = 4;
 		const uint32_t grid = (uint32_t)std::min<uint64_t>((n_vec + waves_per_block - 1) / waves_per_block,
 		                                                   (uint64_t)ctx->n_cus * 8);
-		hipLaunchKernelGGL(polr_tscan_count_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec, packed);
+		hipLaunchKernelGGL(polr_tscan_count_kernel, dim3(grid), dim3(256), 0, st, fs, lip, n_rows, vector_size, n_vec, packed);
 		hipLaunchKernelGGL(polr_tscan_block_sums_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
 		hipLaunchKernelGGL(polr_tscan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, n_blocks, totals);
 		hipLaunchKernelGGL(polr_tscan_apply_kernel, dim3((uint32_t)n_blocks), dim3(1024), 0, st, packed, n_vec, sums);
-		hipLaunchKernelGGL(polr_tscan_write_kernel, dim3(grid), dim3(256), 0, st, fs, n_rows, vector_size, n_vec, packed,
+		hipLaunchKernelGGL(polr_tscan_write_kernel, dim3(grid), dim3(256), 0, st, fs, lip, n_rows, vector_size, n_vec, packed,
 		                   sel, offs, totals);
 		e = hipMemcpyAsync(h_tot, totals, 16, hipMemcpyDeviceToHost, st);
 		e = e == hipSuccess ? hipStreamSynchronize(st) : e;

@@ -31,7 +31,7 @@ EXPORTS = [
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_morsels",
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
-    "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
+    "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
 ]
 
 
@@ -158,12 +158,14 @@ def load():
     L.polr_pipeline_launch_info.argtypes = [vp, C.c_int, vp]
     L.polr_ht_finalize_auto.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
     L.polr_pipeline_scan_filter.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.polr_pipeline_scan_filter_lip.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp]
     L.polr_pipeline_fetch_scan.argtypes = [vp, vp, vp]
     L.polr_mpx_use_scan_chunks.argtypes = [vp]
     L.polr_out_aggregate.argtypes = [vp, vp, vp, u32, vp]
     L.polr_out_aggregate_grouped.argtypes = [vp, vp, vp, u32, vp, u32, vp, C.c_uint64, vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_run_resident_morsels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, u32, vp, u32]
+    L.polr_mpx_run_backpressure.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, vp, u32]
     L.polr_mpx_enable_timing.argtypes = [vp, C.c_int]
     L.polr_mpx_kernel_time.argtypes = [vp, P(C.c_double), P(u64)]
     L.polr_comm_get_unique_id.argtypes = [vp]
@@ -362,16 +364,17 @@ class Pipeline:
         self.ctx.check(self.ctx.L.polr_pipeline_launch_info(self.h, int(materialize), C.byref(i)))
         return {f[0]: getattr(i, f[0]) for f in LaunchInfo._fields_}
 
-    def scan_filter(self, filters, vector_size=1024, stream=None):
-        """polr_pipeline_scan_filter: filters = [(col, op, constant)] with op in CMP; the selection and the chunk
-        boundaries stay on the device -> (n_selected, n_chunks)"""
+    def scan_filter(self, filters, vector_size=1024, stream=None, lip_joins=0):
+        """polr_pipeline_scan_filter(_lip): filters = [(col, op, constant)] with op in CMP; lip_joins: bit j = also
+        apply join j's filter at the source (LIP); the selection and the chunk boundaries stay on the device ->
+        (n_selected, n_chunks)"""
         n = len(filters)
         arr = (ScanFilter * max(n, 1))()
         for i, (col, op, const) in enumerate(filters):
             arr[i].col, arr[i].op, arr[i].constant = col, CMP[op] if isinstance(op, str) else op, int(const or 0)
         ns, nc = C.c_uint64(), C.c_uint64()
-        self.ctx.check(self.ctx.L.polr_pipeline_scan_filter(self.h, stream, arr if n else None, n, vector_size,
-                                                            C.byref(ns), C.byref(nc)))
+        self.ctx.check(self.ctx.L.polr_pipeline_scan_filter_lip(self.h, stream, arr if n else None, n, int(lip_joins),
+                                                                vector_size, C.byref(ns), C.byref(nc)))
         self.scan = (ns.value, nc.value)
         return self.scan
 
@@ -608,6 +611,15 @@ def run_resident_morsels(mpxs, chunk_begin, chunk_end, morsel_chunks=120, out=No
                                                   out.h if out else None,
                                                   (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) |
                                                   ((share & 0xFF) << 8 if share > 1 else 0)))
+
+
+def run_backpressure(mpxs, chunk_begin, chunk_end, morsel_chunks=120, out=None, reset=True, finish=True):
+    """polr_mpx_run_backpressure: one executor per join order racing for morsels of the source"""
+    ctx = mpxs[0].ctx
+    n = len(mpxs)
+    hs = (C.c_void_p * n)(*[m.h for m in mpxs])
+    ctx.check(ctx.L.polr_mpx_run_backpressure(hs, None, chunk_begin, chunk_end, morsel_chunks, out.h if out else None,
+                                              (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0)))
 
 
 def finish_many(mpxs):

@@ -216,6 +216,16 @@ typedef struct polr_scan_filter {
 } polr_scan_filter;
 int polr_pipeline_scan_filter(polr_pipeline *p, void *stream, const polr_scan_filter *filters, uint32_t n_filters,
                               uint32_t vector_size, uint64_t *n_selected, uint64_t *n_chunks);
+/* The same scan with LIP (`PRAGMA enable_lip`, lookahead information passing): the source chunks are additionally
+ * thinned by the filters of the joins named in `lip_joins` (bit j = join j) before they enter the pipeline --
+ * PipelineExecutor::FetchFromSource src/parallel/pipeline_executor.cpp:396-465 probing
+ * PhysicalHashJoin::ProbeBloomFilter physical_hash_join.cpp:579-635 for every join with build_bloom_filter
+ * (eligibility physical_join.cpp:57-107: one condition, key traced back to a source column).  The reference's filter is
+ * a bloom filter sized from a planner estimate; here it is the join's own index (no false positives): the survivors are
+ * a subset of the reference's, the pipeline's output rows are the same.  POLR_E_INVALID for a join that is not keyed
+ * by one source column. */
+int polr_pipeline_scan_filter_lip(polr_pipeline *p, void *stream, const polr_scan_filter *filters, uint32_t n_filters,
+                                  uint32_t lip_joins, uint32_t vector_size, uint64_t *n_selected, uint64_t *n_chunks);
 /* read the scan result back (tests): sel[n_selected], chunk_offsets[n_chunks + 1]; either may be NULL */
 int polr_pipeline_fetch_scan(polr_pipeline *p, uint32_t *sel, uint64_t *chunk_offsets);
 /* Refresh the cells of probe column `col` in place (a new DataChunk arriving at the operator-level
@@ -377,6 +387,15 @@ int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_beg
  * and total intermediates are not. */
 int polr_mpx_run_resident_morsels(polr_mpx **ms, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
                                   uint32_t morsel_chunks, uint32_t n, polr_out *out, uint32_t flags);
+/* MultiplexerRouting::BACKPRESSURE (src/parallel/pipeline.cpp:147-156, src/parallel/polar_config.cpp:128-147): the
+ * reference schedules ONE task per join order over a single shared source state, so the join orders race for the
+ * source and the cheaper ones end up with more of it.  ms: one multiplexer per join order of the pipeline (created with
+ * POLR_ROUTE_BACKPRESSURE); executor i sends every morsel it pulls (morsel_chunks source chunks at a time; 120 = a row
+ * group) down join order i.  Row set and COUNT(*) are deterministic, the split between the orders depends on timing
+ * (as in the reference).  Statistics: executor i reports its tuples under path 0 of ITS statistics, its per-stage
+ * counters under path i. */
+int polr_mpx_run_backpressure(polr_mpx **ms, void *stream, uint64_t chunk_begin, uint64_t chunk_end,
+                              uint32_t morsel_chunks, polr_out *out, uint32_t flags);
 int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_chunks);
 /* fresh MultiplexerState (a new PipelineExecutor / a new pass over the source) */
 int polr_mpx_reset(polr_mpx *m, void *stream);

@@ -155,3 +155,84 @@ def test_two_pool_runs_side_by_side(gpu_ctx):
     for m in (ref, a, b):
         m.close()
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("morsel_chunks", [8, 120])
+def test_backpressure_join_orders_race_for_morsels(gpu_ctx, morsel_chunks):
+    """MultiplexerRouting::BACKPRESSURE: one executor per join order over one shared morsel cursor (pipeline.cpp:147-156).
+    Which order gets which morsel depends on timing; every tuple is probed exactly once, COUNT(*) is the reference's, and
+    an executor only ever uses ITS join order."""
+    from polr_amd import capi
+    wl, paths, c = workload("q4.1/3")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    k, P = len(wl["joins"]), len(paths)
+    mpxs = [capi.DeviceMultiplexer(pipe, "backpressure") for _ in range(P)]
+    capi.run_backpressure(mpxs, 0, n_chunks, morsel_chunks)
+    stats = capi.finish_many(mpxs)
+    assert sum(sum(st["input_tuple_count_per_path"]) for st in stats) == n
+    total = 0
+    for p, st in enumerate(stats):
+        for q in range(P):
+            if q != p:
+                assert not any(st["stage_out"][q]), (p, q)  # executor p only ever ran join order p
+        total += st["stage_out"][p][k - 1]
+    assert total == c["count_star"]
+    for m in mpxs:
+        m.close()
+    pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mask", [0b0010, 0b1111, 0b0101])
+def test_lip_prefilter_keeps_the_result(gpu_ctx, mask):
+    """`PRAGMA enable_lip` on the device: the filters of the joins named in the mask thin the source chunks before the
+    multiplexer sees them.  The survivors are exactly the rows whose key is on the build side of every such join (the
+    device's filters are the joins' own indexes: no false positives), the thinned chunks keep the scan's boundaries, and
+    the pipeline's COUNT(*) is unchanged -- what LIP must never change."""
+    from polr_amd import capi
+    wl, paths, c = workload("q4.1/3")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    names = list(wl["probe"]["cols"].keys())
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_sel, n_chunks = pipe.scan_filter([], lip_joins=mask)
+    keep = np.ones(n, dtype=bool)
+    for j, jn in enumerate(wl["joins"]):
+        if (mask >> j) & 1:
+            keep &= np.isin(cols[jn["key_src"][0][1]], jn["keys"][0])
+    want = np.nonzero(keep)[0].astype(np.uint32)
+    sel, offs = pipe.fetch_scan()
+    assert n_sel == len(want) and np.array_equal(sel, want)
+    import bench
+    assert np.array_equal(offs, bench.chunk_offsets_for(want, n, 1024))
+    k, P = len(wl["joins"]), len(paths)
+    for routing in ("adaptive_reinit", "default_path"):
+        mpx = capi.DeviceMultiplexer(pipe, routing)
+        mpx.use_scan_chunks()
+        capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+        st = mpx.finish()
+        assert sum(st["stage_out"][p][k - 1] for p in range(P)) == c["count_star"]
+        assert sum(st["input_tuple_count_per_path"]) == n_sel
+        if mask == 0b1111 and routing == "default_path":
+            # every join's filter was applied at the source: nothing is dropped inside the pipeline any more
+            assert st["num_intermediates"] == n_sel * k and n_sel == c["count_star"]
+        mpx.close()
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_lip_rejects_a_dependent_join(gpu_ctx):
+    from polr_amd import capi, workloads
+    wl = workloads.chain_dep(n_fact=20_000)
+    joins = capi.build_joins(gpu_ctx, wl)
+    cols = list(wl["probe"]["cols"].values())
+    pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, [[0, 1, 2]])
+    with pytest.raises(capi.PolrError):
+        pipe.scan_filter([], lip_joins=0b010)  # join 1 is keyed by a build column of join 0
+    pipe.close()
