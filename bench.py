@@ -543,7 +543,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             mt = [v for kk, v in cpu.items() if kk.startswith("count_star_threads_") and kk != "count_star_threads_1"]
             if mt and c1 is not None and any(v != c1 for v in mt):
                 rec["reference_multithreaded_count_differs"] = True
-        if is_ssb and cpu and cpu.get("sample_count_star") and world == 1:
+        if is_ssb and cpu and cpu.get("sample_count_star") and world == 1 and not device_scan:
             # parity at full size: the device's COUNT(*) over the same contiguous samples the reference ran on
             dev_counts = []
             m = capi.DeviceMultiplexer(pipe, routing, chunk_size=V, regret_budget=budget,
