@@ -414,6 +414,26 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             launches += n_e
             m.enable_timing(False)
 
+    # ---- diagnostic only (POLR_DIAG_TIMELINE=<file.npz>, needs `make -C duckdb-polr_amd diag`): one more pass with the
+    # instrumented pool kernels; per probe wave and unit {began waiting, got it, finished, exec/path/count}
+    if os.environ.get("POLR_DIAG_TIMELINE"):
+        import ctypes as C
+        cap_tl = 4096
+        n_waves = 256 * 16
+        tl = torch.zeros(n_waves * cap_tl * 4, dtype=torch.int64, device=dev)
+        kk = 2 if k <= 2 else 4 if k <= 4 else 6 if k <= 6 else 8
+        fn = getattr(ctx.L, "polr_diag_timeline_set_k%d" % kk)
+        fn.argtypes = [C.c_void_p, C.c_uint32]
+        if fn(tl.data_ptr(), cap_tl) != 0:
+            raise SystemExit("polr_diag_timeline_set failed")
+        step()
+        torch.cuda.synchronize()
+        fn(None, 0)
+        arr = tl.cpu().numpy().reshape(n_waves, cap_tl, 4)
+        used = (arr[:, :, 2] != 0).sum(axis=1)
+        keep = int(used.max()) if used.size else 0
+        np.savez_compressed(os.environ["POLR_DIAG_TIMELINE"], tl=arr[:, :keep, :], used=used)
+
     # ---- the reference's harness artefacts (benchmark_runner --log_tuples_routed --measure_pipeline --dir_prefix
     # --nruns, benchmark/benchmark_runner.cpp:215-355): tmp/<prefix><ts>.csv, -intms.txt, -enumeration.csv per executor
     # (the reference writes one set per worker thread), tmp/<prefix><ts>-<hash>.csv per run; outside the timed region
@@ -745,6 +765,9 @@ def run_job_full(args, env, steps, warmup, with_cpu):
 
 
 def main():
+    if os.environ.get("POLR_DIAG_TIMELINE"):
+        from polr_amd import capi as _capi
+        _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), "libpolr_hip_diag.so")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

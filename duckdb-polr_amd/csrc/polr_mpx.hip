@@ -622,7 +622,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	// when at least a executors were still routing, so all their lo units together are at most 8 x pool_waves + 34 a;
 	// a hi round has at most POLR_POOL_HI_TUPLES / 64 units.  Twice that, plus the EXIT entries.
 	uint32_t n_rings = 1;
-	while (n_rings * 2 <= std::min<uint32_t>(POLR_POOL_RINGS, n_workers)) {
+	while (n_rings * 2 <= std::min<uint32_t>(POLR_POOL_RINGS, pool_waves)) {
 		n_rings *= 2;
 	}
 	const uint64_t R = n_rings;
@@ -673,7 +673,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		// the SF100 run: 2.29 ms with 64-tuple units, 1.77 ms with 512)
 		{
 			// the fewest probe waves any ring has; the lottery divides them into at most 8 classes
-			const uint32_t min_waves = (n_workers / n_rings) * wpb;
+			const uint32_t min_waves = pool_waves / n_rings;
 			uint32_t lot = 1;
 			while (lot * 2 <= std::min<uint32_t>(8, min_waves)) {
 				lot *= 2;
@@ -687,7 +687,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		hr->hi_unit = hu_env >= 64 && hu_env <= 1024 && hu_env % 64 == 0 ? (uint32_t)hu_env : (flat ? 512u : 256u);
 	}
 	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {
-		hr->worker_waves[r] = r < n_rings ? ((n_workers + n_rings - 1 - r) / n_rings) * wpb : 0u;
+		hr->worker_waves[r] = r < n_rings ? (pool_waves + n_rings - 1 - r) / n_rings : 0u; // (wave g serves ring g % n_rings)
 	}
 	hr->pool_waves = pool_waves;
 	hr->lo_cap = m0->pool_lo_cap;

@@ -24,6 +24,9 @@
 #include "polr_flat_device.h"
 #include "polr_pool_device.h"
 
+#define PASTE_TL2(a, b) a##b
+#define PASTE_TL(a, b) PASTE_TL2(a, b)
+
 // LDS a router wave needs: state + round scratch | saved state of a rehearsal | window of >= 256 chunk boundaries
 #define POOL_ROUTER_STATE ((POLR_RES_ROUTER_DWORDS + 3u) & ~3u)
 #define POOL_ROUTER_SAVE ((POLR_RES_HOT_DWORDS + 3u) & ~3u)
@@ -85,6 +88,39 @@ __device__ __forceinline__ void pool_router_wave(const ResidentExec *execs, Pool
 	                 cache_dwords / 2, base + POOL_ROUTER_STATE);
 }
 
+// diagnostic build only (-DPOLR_DIAG_TIMELINE, `make diag`; never compiled into the product): every probe wave writes
+// {began waiting, got the unit, finished it, exec << 40 | path << 32 | count} per unit, 100 MHz wall clock
+#ifdef POLR_DIAG_TIMELINE
+static __device__ unsigned long long *polr_diag_tl;
+static __device__ uint32_t polr_diag_tl_cap;
+#define TL_BEGIN(first_block_)                                                                                         \
+	unsigned long long tl_wait = wall_clock64();                                                                       \
+	unsigned long long tl_got = 0;                                                                                     \
+	uint32_t tl_n = 0;                                                                                                 \
+	const uint32_t tl_wave = (blockIdx.x - (first_block_)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+#define TL_GOT tl_got = wall_clock64();
+#define TL_DONE(u_)                                                                                                    \
+	if (polr_diag_tl && tl_n < polr_diag_tl_cap && (threadIdx.x & 63) == 0) {                                          \
+		unsigned long long *r_ = polr_diag_tl + ((size_t)tl_wave * polr_diag_tl_cap + tl_n) * 4;                       \
+		r_[0] = tl_wait;                                                                                               \
+		r_[1] = tl_got;                                                                                                \
+		r_[2] = wall_clock64();                                                                                        \
+		r_[3] = ((unsigned long long)(u_).exec << 40) | ((unsigned long long)(u_).path << 32) | (u_).count;            \
+	}                                                                                                                  \
+	tl_n++;                                                                                                            \
+	tl_wait = wall_clock64();
+extern "C" int PASTE_TL(polr_diag_timeline_set_k, POLR_K)(unsigned long long *buf, uint32_t cap) {
+	if (hipMemcpyToSymbol(HIP_SYMBOL(polr_diag_tl), &buf, sizeof(buf)) != hipSuccess) {
+		return -1;
+	}
+	return hipMemcpyToSymbol(HIP_SYMBOL(polr_diag_tl_cap), &cap, sizeof(cap)) == hipSuccess ? 0 : -1;
+}
+#else
+#define TL_BEGIN(first_block_)
+#define TL_GOT
+#define TL_DONE(u_)
+#endif
+
 // a probe wave reports a finished unit: its stage counters (returning atomics), then the arrival
 template <int K>
 __device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const PoolUnit &u, uint32_t ring, uint32_t k,
@@ -123,7 +159,11 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 		pool_router_wave(execs, run, rh, k, 256, lds, lds_per_wave);
 		return;
 	}
-	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) & (rh.n_rings - 1u);
+	// probe wave g of the pool serves ring g % n_rings (dealt wave by wave, not workgroup by workgroup: the units of a
+	// round go to all rings alike, so every ring needs the same number of waves -- 240 workgroups over 64 rings left a
+	// quarter of the rings with 3 workgroups instead of 4, and every round waited for those)
+	const uint32_t pool_wave = (blockIdx.x - rh.n_router_blocks) * (blockDim.x >> 6) + wave_in_block;
+	const uint32_t ring = pool_wave & (rh.n_rings - 1u);
 	WaveCtx<W, K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
@@ -153,9 +193,11 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 	uint32_t cur_path = 0xFFFFFFFFu;
 	unsigned long long lo_ticket = ~0ull, mid_ticket = ~0ull;
 	PoolUnit u;
-	const uint32_t wave_in_ring = ((blockIdx.x - rh.n_router_blocks) / rh.n_rings) * (blockDim.x >> 6) + wave_in_block;
+	const uint32_t wave_in_ring = pool_wave / rh.n_rings;
+	TL_BEGIN(rh.n_router_blocks)
 	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, wave_in_ring, rh.hi_lottery, lo_ticket, mid_ticket,
 	                           u, c.lane)) {
+		TL_GOT
 		if (u.path != cur_path) {
 			const uint32_t *src = (const uint32_t *)(stages + (uint64_t)u.path * POLR_KMAX);
 			uint32_t *dst = (uint32_t *)c.desc;
@@ -171,6 +213,7 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 		run_until_idle(c, false);
 		run_until_idle(c, true);
 		pool_arrive<K>(execs, u, ring, c.k, c.cnt, c.lane);
+		TL_DONE(u)
 	}
 	if (c.cur_chunk != NO_CHUNK && c.lane == 0) {
 		out.chunk_count[c.cur_chunk] = c.fill;
@@ -204,7 +247,11 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		}
 		__syncthreads();
 	}
-	const uint32_t ring = (blockIdx.x - rh.n_router_blocks) & (rh.n_rings - 1u);
+	// probe wave g of the pool serves ring g % n_rings (dealt wave by wave, not workgroup by workgroup: the units of a
+	// round go to all rings alike, so every ring needs the same number of waves -- 240 workgroups over 64 rings left a
+	// quarter of the rings with 3 workgroups instead of 4, and every round waited for those)
+	const uint32_t pool_wave = (blockIdx.x - rh.n_router_blocks) * (blockDim.x >> 6) + wave_in_block;
+	const uint32_t ring = pool_wave & (rh.n_rings - 1u);
 	FlatCtx<K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
@@ -227,9 +274,11 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 	uint32_t cur_path = 0xFFFFFFFFu;
 	unsigned long long lo_ticket = ~0ull, mid_ticket = ~0ull;
 	PoolUnit u;
-	const uint32_t wave_in_ring = ((blockIdx.x - rh.n_router_blocks) / rh.n_rings) * (blockDim.x >> 6) + wave_in_block;
+	const uint32_t wave_in_ring = pool_wave / rh.n_rings;
+	TL_BEGIN(rh.n_router_blocks)
 	while (polr_pool_next_unit(run, rh.sync, ring, rh.lo_cap, rh.hi_cap, wave_in_ring, rh.hi_lottery, lo_ticket, mid_ticket,
 	                           u, c.lane)) {
+		TL_GOT
 		c.pf_pos = ~0ull; // (a prefetch belongs to one unit of one join order)
 		if (u.path != cur_path) {
 #pragma unroll
@@ -245,6 +294,7 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		c.in_end = (uint64_t)u.begin + u.count;
 		flat_run_unit<K>(c);
 		pool_arrive<K>(execs, u, ring, c.k, c.cnt, c.lane);
+		TL_DONE(u)
 	}
 }
 

@@ -10,8 +10,9 @@
 // of one executor therefore run beside the table-sized rounds of the others instead of idling a fixed slice of
 // the grid, and a skewed source range only makes its executor finish later, not its share of the device.
 //
-//   rings     POLR_POOL_RINGS (64) x {hi, lo}: FIFO of 16-byte unit entries.  Worker waves of workgroup b use ring
-//             b % 64; three queues per ring, see PoolRoundOut (64 rings keep the pollers of one control line few: with 8 rings, 512 idle waves per ring answered
+//   rings     POLR_POOL_RINGS (64) x {hi, mid, lo}: FIFO of 16-byte unit entries.  Probe wave g of the pool uses ring
+//             g % 64 (every ring the same number of waves); three queues per ring, see PoolRoundOut (64 rings keep the
+//             pollers of one control line few: with 8 rings, 512 idle waves per ring answered
 //             every small round with a storm of compare-and-swaps on one word -- measured 8 us per round, serialised over
 //             all executors).  Routers deal the units of a round round-robin over the rings.  hi = rounds of <= POLR_POOL_HI_TUPLES tuples (exploration
 //             slices: latency-critical, taken first), lo = everything else.
