@@ -348,7 +348,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                 m.set_chunk_offsets(offs)
             execs.append((m, (e * n_chunks) // E, ((e + 1) * n_chunks) // E))
         sets.append(execs)
-    results = [None] * E
+    raw_results = [None]
     ranges = [(x[1], x[2]) for x in sets[0]]
     all_mpxs = [x[0] for ex in sets for x in ex]
     step_no = [0]
@@ -364,10 +364,11 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             capi.run_resident(cur, ranges, reset=True, finish=True, share=P)
         if fetch:
             for ex in sets:  # (settles every stream; the statistics reported are the last pass's)
-                got = capi.finish_many([x[0] for x in ex])
+                ms_ = [x[0] for x in ex]
+                got = capi.finish_many_raw(ms_)  # the C structs; read out as dictionaries once the clock has stopped
                 if ex[0][0] is cur[0]:
-                    results[:] = got
-        return results
+                    raw_results[0] = (got, ms_)
+        return raw_results
 
     def merged(res):
         out = {"num_intermediates": 0, "num_rounds": 0, "input_tuple_count_per_path": [0] * len(paths),
@@ -394,6 +395,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     dt = time.perf_counter() - t0  # this rank's K steps; the job's time is the MAX over ranks (below)
     if world > 1:
         dist.barrier()
+    results = capi.stats_dicts(*raw_results[0])
     st = merged(results)
     # ---- same K steps again with a HIP event pair around every pool-kernel launch (on the launch stream) to get the
     # dominant kernel's device time for the roofline; kept out of the region `value` is computed from

@@ -215,7 +215,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 	e = e == hipSuccess ? hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) : e;
 	e = e == hipSuccess ? hipMemset(m->ticket_dev, 0, 64) : e;
 	// two counter banks (a resident run keeps up to two rounds in flight; everything else uses the first)
-	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, 2 * POLR_NSHARD * POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&m->counts_dev, POLR_SLOTS * POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_path, max_log * 4) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_tuples, max_log * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->log_inter, max_log * 8) : e;
@@ -224,7 +224,7 @@ int polr_mpx_create(polr_pipeline *p, const polr_mpx_config *cfg, polr_mpx **out
 		memset(m->done_host, 0, 64);
 		e = hipHostGetDevicePointer((void **)&m->progress_dev, m->done_host, 0);
 	}
-	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, 2 * POLR_NSHARD * POLR_KMAX * 8) : e;
+	e = e == hipSuccess ? hipMemset(m->counts_dev, 0, POLR_SLOTS * POLR_NSHARD * POLR_KMAX * 8) : e;
 	e = e == hipSuccess ? hipMalloc((void **)&m->sync_dev, sizeof(ResidentSync)) : e;
 	e = e == hipSuccess ? hipHostMalloc((void **)&m->stats_host, sizeof(polr_mpx_stats), hipHostMallocMapped) : e;
 	e = e == hipSuccess ? hipHostGetDevicePointer((void **)&m->stats_host_dev, m->stats_host, 0) : e;
@@ -618,8 +618,8 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	// entries, with a factor of two to spare
 	const uint32_t pool_waves = n_workers * wpb;
 	// Rings in use: every ring must have probe waves that serve it.  Ring capacity: a round of U units leaves at most
-	// U / R + 1 entries on a ring; the executors that have rounds in flight (a of them, two rounds each) published them
-	// when at least a executors were still routing, so all their lo units together are at most 8 x pool_waves + 34 a;
+	// U / R + 1 entries on a ring; the executors that have rounds in flight (a of them, at most POLR_SLOTS rounds each) published them
+	// when at least a executors were still routing, so all their lo units together are at most POLR_SLOTS x (4 x pool_waves + 17 a);
 	// a hi round has at most POLR_POOL_HI_TUPLES / 64 units.  Twice that, plus the EXIT entries.
 	uint32_t n_rings = 1;
 	while (n_rings * 2 <= std::min<uint32_t>(POLR_POOL_RINGS, pool_waves)) {
@@ -627,9 +627,11 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	}
 	const uint64_t R = n_rings;
 	// (+ a round larger than target x 65 536 tuples has tuples / 65 536 units)
-	const uint32_t lo_cap = next_pow2_u32(2ull * ((8ull * pool_waves + 34ull * n + 2ull * (p->n_tuples >> 16)) / R + 2ull * n +
-	                                              pool_waves / R + 16) + 64);
-	const uint32_t hi_cap = next_pow2_u32(2ull * (2ull * n * (POLR_POOL_HI_TUPLES / POLR_POOL_HI_UNIT / R + 1)) + 64);
+	const uint32_t lo_cap = next_pow2_u32(2ull * ((4ull * POLR_SLOTS * pool_waves + 17ull * POLR_SLOTS * n +
+	                                               (uint64_t)POLR_SLOTS * (p->n_tuples >> 16)) / R +
+	                                              (uint64_t)POLR_SLOTS * n + pool_waves / R + 16) + 64);
+	const uint32_t hi_cap =
+	    next_pow2_u32(2ull * ((uint64_t)POLR_SLOTS * n * (POLR_POOL_HI_TUPLES / POLR_POOL_HI_UNIT / R + 1)) + 64);
 	if (!m0->pool_dev || m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap || m0->pool_dirty) {
 		if (m0->pool_dev && (m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap)) {
 			HIPCHK(ctx, hipStreamSynchronize(st));
@@ -717,13 +719,10 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ex[i].chunk_offsets = m->chunk_offsets_dev;
 		ex[i].n_chunks = m->n_chunks;
 		ex[i].n_tuples = p->n_tuples;
-		ex[i].epoch = 0; // (the pool protocol has no epochs: tickets are monotonic across runs)
 		ex[i].flags = flags;
-		ex[i].registered = 0;
 		ex[i].pad = 0;
 		ex[i].stats_out = m->stats_host_dev;
 		m->stats_in_host = (flags & POLR_RUN_FINISH) != 0;
-		ex[i].stamps = nullptr;
 		((volatile uint32_t *)m->done_host)[1] = 0;
 	}
 	// A pass that repeats the previous one (same executors, ranges, flags: every step of a measurement loop) finds its
@@ -829,7 +828,7 @@ int polr_mpx_reset(polr_mpx *m, void *stream) {
 		m->pending_sync = false;
 	}
 	m->stats_in_host = false;
-	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, 2 * POLR_NSHARD * POLR_KMAX * 8, st));
+	HIPCHK(ctx, hipMemsetAsync(m->counts_dev, 0, POLR_SLOTS * POLR_NSHARD * POLR_KMAX * 8, st));
 	hipLaunchKernelGGL(polr_mpx_init_kernel, dim3(1), dim3(1), 0, st, m->dev, m->cfg, m->pipe->n_paths,
 	                   m->pipe->n_tuples, m->n_chunks, m->log_path, m->log_tuples, m->log_inter, m->wide0_mask,
 	                   m->progress_dev, ((volatile uint32_t *)m->done_host)[0]);

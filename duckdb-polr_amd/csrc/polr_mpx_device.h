@@ -12,6 +12,8 @@
 #include "polr_device.h"
 #include "polr_routing.h"
 
+#define POLR_SLOTS 4 // rounds one executor can have in flight in a one-launch run (see ResidentSync)
+
 struct DevMpx {
 	polr::MultiplexerCore core;
 	uint64_t chunk_idx, chunk_end;
@@ -36,10 +38,10 @@ struct DevMpx {
 	polr_mpx_config cfg;
 	uint32_t n_paths;
 	// bookkeeping of resident runs, carried from run to run so that a run starts without extra round trips:
-	// res_valid: res_target[] are the current sums of the two arrival counters and counter bank 1 is empty
+	// res_valid: res_target[] are the current sums of the arrival counters and the counter banks beyond 0 are empty
 	// (false after a run that was given up -- the next one re-reads and drops)
 	uint32_t res_valid;
-	unsigned long long res_target[2];
+	unsigned long long res_target[POLR_SLOTS];
 	uint64_t stage_out[POLR_MAX_PATHS][POLR_MAX_JOINS];
 };
 
@@ -279,42 +281,18 @@ __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, ui
 }
 
 
-// ==== resident launch: one kernel routes and probes a whole run ======================================
-// Executors (multiplexer + its share of the source chunks) are laid over the grid by blockIdx % n_exec,
-// which is also how the hardware deals workgroups to the 8 XCDs: with 8 executors every executor lives on
-// its own XCD and its sync words stay in that XCD's L2.  Workgroup 0 of an executor is its router (one
-// wave, multiplexer state in LDS for the whole run); the other workgroups are probe workers.  Router and
-// workers talk through two tagged 64-bit words and one arrival counter, all with relaxed agent-scope
-// atomics -- no fences, no host.
-//
-//   word_a = epoch:12 | round:20 | count:32     count = tuples of the round; POLR_RES_DONE = run over
-//   word_b = tag:8 | n_blocks:12 | emit:1 | path:5 | unit_size/64:6 | begin:32
-//            tag = (epoch & 15) << 4 | (round & 15); n_blocks = worker workgroups the round is dealt to
-//
-// A worker waits for word_a to show its epoch and a round number other than the one it processed last,
-// then for word_b to carry the matching tag (the two stores need no order).  Worker workgroups REGISTER when
-// they start (atomic counter, zeroed with the descriptor copy of every run): the registration order is their
-// rank, and the router deals the units of a round statically over the workgroups registered so far (unit u ->
-// workgroup u mod n_blocks, wave (u / n_blocks) mod waves).  Nothing ever waits for a workgroup that is not
-// running yet, so a device shared with other kernels (two resident runs at once, foreign work) only makes
-// rounds narrower, it cannot deadlock them.  Only workers that own a unit of the round touch anything but
-// their poll word; they add the units they finished to the arrival counter after their counter atomics have
-// returned.  The router waits for the arrivals to reach the running total, absorbs the counters, routes.
-#define POLR_RES_DONE 0xFFFFFFFFu
+// ==== one-launch runs: what a router and the probe pool share per executor ==========================
+// (protocol: polr_pool_device.h)
 #define POLR_RES_TIMEOUT_TICKS 400000000ull // 4 s of the 100 MHz wall clock: a wait this long is a lost run
 
-#define POLR_RES_COPIES 64 // the round words are published in 64 copies (one per router lane, own cache line)
-#define POLR_RES_ARRIVE 32 // arrival counter shards (own cache line each)
-// Two round SLOTS per executor: while the workers probe round r the router may already have published round
-// r+1 in the other slot when its decision cannot depend on r's intermediates (the exploration rounds of an init
-// phase, ALTERNATE): two dependent-latency rounds overlap.  Each slot has its own words, counter bank and arrivals.
+// Round SLOTS per executor: while the pool probes round r the router may already have published the rounds after it
+// whose decisions cannot depend on the intermediates still outstanding (the exploration rounds of an init phase,
+// ALTERNATE): up to POLR_SLOTS dependent-latency rounds overlap.  Each slot has its own counter bank and arrivals.
+#define POLR_ARRIVE_SHARDS 8 // arrival counters and counter banks are sharded (ring & 7), a cache line each
 struct ResidentSync {
 	struct {
-		unsigned long long a[2], b[2], pad[4];
-	} pub[POLR_RES_COPIES]; // workgroup w polls copy w % 64: a few pollers per line instead of a thousand
-	struct {
 		unsigned long long v, pad[7];
-	} arrived[2][POLR_RES_ARRIVE]; // per slot; monotonic across runs; the router sums the shards
+	} arrived[POLR_SLOTS][POLR_ARRIVE_SHARDS]; // per slot; monotonic across runs; the router sums the shards
 };
 
 struct ResidentExec {
@@ -324,9 +302,7 @@ struct ResidentExec {
 	uint64_t chunk_begin, chunk_end;
 	const uint64_t *chunk_offsets;
 	uint64_t n_chunks, n_tuples;
-	uint32_t epoch; // 12 bits, host-incremented per run
 	uint32_t flags; // POLR_RUN_RESET | POLR_RUN_FINISH
-	uint32_t registered; // worker workgroups of this executor that have started (zero when the run is enqueued)
 	uint32_t pad;
 	polr_mpx_stats *stats_out; // POLR_RUN_FINISH: where the closing statistics go (pinned host memory)
 	// morsel mode (morsel_cursor != nullptr): the executors of the run share the chunk range up to morsel_end and
@@ -336,31 +312,10 @@ struct ResidentExec {
 	uint64_t morsel_end;
 	uint32_t morsel_chunks;
 	uint32_t path_plus1; // BACKPRESSURE: this executor sends everything down join order path_plus1 - 1 (0: as routed)
-	unsigned long long *stamps; // diagnostic builds only (POLR_DIAG_STAMPS), else nullptr
 };
-
-#ifdef POLR_DIAG_STAMPS
-#define RES_STAMP(x_, round_, i_)                                                                                      \
-	if ((x_).stamps && (round_) < 1024) {                                                                              \
-		(x_).stamps[(uint64_t)(round_) * 8 + (i_)] = wall_clock64();                                                   \
-	}
-#else
-#define RES_STAMP(x_, round_, i_)
-#endif
 
 #define POLR_RES_HOT_DWORDS (offsetof(DevMpx, stage_out) / 4)
 #define POLR_RES_ROUTER_DWORDS (POLR_RES_HOT_DWORDS + 32)
-
-__device__ __forceinline__ unsigned long long polr_res_word_a(uint32_t epoch, uint32_t round, uint32_t count) {
-	return ((unsigned long long)(epoch & 0xFFFu) << 52) | ((unsigned long long)(round & 0xFFFFFu) << 32) | count;
-}
-__device__ __forceinline__ uint32_t polr_res_tag(uint32_t epoch, uint32_t round) {
-	return ((epoch & 15u) << 4) | (round & 15u);
-}
-__device__ __forceinline__ uint32_t polr_res_next_round(uint32_t round) {
-	round = (round + 1) & 0xFFFFFu;
-	return round == 0 ? 1 : round; // 0 is the workers' "nothing seen yet"
-}
 
 // PushFinalize's closing FinalizePathRun (polar_pipeline_executor.cpp:150-151); lane 0 of the caller,
 // counters already absorbed.  m: the state being worked on (LDS copy or HBM)
@@ -397,18 +352,6 @@ __device__ __forceinline__ void polr_write_stats(const DevMpx *m, DevMpx *mg, po
 		}
 		stats->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = v;
 	}
-}
-
-// sum of the arrival shards, the same value in every lane (full wave)
-__device__ __forceinline__ unsigned long long polr_res_arrived(ResidentSync *sync, uint32_t slot, uint32_t lane) {
-	unsigned long long v = 0;
-	if (lane < POLR_RES_ARRIVE) {
-		v = __hip_atomic_load(&sync->arrived[slot][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-	for (int d = 16; d > 0; d >>= 1) {
-		v += __shfl_xor(v, d, 64);
-	}
-	return __shfl(v, 0, 64);
 }
 
 // (re)load the LDS window of chunk boundaries starting at chunk `from`; full wave
@@ -474,333 +417,5 @@ __device__ __forceinline__ bool polr_can_speculate(const volatile polr::Multiple
 	}
 	default:
 		return false;
-	}
-}
-
-// The router of one executor: ONE full wave, for the whole run.  lds: POLR_RES_ROUTER_DWORDS dwords.
-// cache_lds / cache_cap: the router workgroup's (otherwise unused) dynamic LDS, in 8-byte entries.
-// registered: the executor's registration counter; expected_blocks: worker workgroups of this executor in the grid;
-// wpb: waves per worker workgroup.
-__device__ __forceinline__ void polr_resident_router(const ResidentExec &x, uint32_t k, uint32_t *registered,
-                                                     uint32_t expected_blocks, uint32_t wpb, uint32_t lane,
-                                                     uint32_t *lds, uint64_t *cache_lds, uint32_t cache_cap,
-                                                     uint32_t *scratch_lds) {
-	DevMpx *mg = x.mpx;
-	if (lane == 0) {
-		RES_STAMP(x, 0, 5)
-	}
-	const bool reset = (x.flags & POLR_RUN_RESET) != 0;
-	// Three independent round trips issued together at entry: the registration counter, the drop of counter bank 0
-	// for a reset run (results never read: fire and forget; it has long been performed when the first round goes
-	// out, several waited-for loads later), and the state load below.
-	uint32_t reg_early = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	if (reset) {
-		for (uint32_t j0 = 0; j0 < k; j0 += 2) {
-			const uint32_t j = j0 + (lane >> 5);
-			if (j < k) {
-				(void)atomicExch(&x.counts[(uint64_t)(lane & 31u) * k + j], 0ull);
-			}
-		}
-	}
-	{
-		// (independent loads, all in flight together: a plain copy loop waits for every load before the next)
-		const uint32_t *src = (const uint32_t *)mg;
-		constexpr uint32_t kPer = (POLR_RES_HOT_DWORDS + 63) / 64;
-		uint32_t v[kPer];
-#pragma unroll
-		for (uint32_t j = 0; j < kPer; j++) {
-			const uint32_t i = j * 64 + lane;
-			v[j] = i < POLR_RES_HOT_DWORDS ? src[i] : 0u;
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < kPer; j++) {
-			const uint32_t i = j * 64 + lane;
-			if (i < POLR_RES_HOT_DWORDS) {
-				lds[i] = v[j];
-			}
-		}
-	}
-	DevMpx *m = (DevMpx *)lds;
-	// nobody on the host follows the steps of a resident run: keep the (PCIe) progress stores off the routing
-	// path; the pointer is restored before the state goes back to HBM
-	volatile uint32_t *const host_words = mg->progress;
-	__builtin_amdgcn_wave_barrier();
-	if (lane == 0) {
-		m->progress = nullptr;
-	}
-	DevRound *round = (DevRound *)(lds + POLR_RES_HOT_DWORDS); // 24 bytes
-	uint64_t *prefix = (uint64_t *)(lds + POLR_RES_HOT_DWORDS + 8);
-	uint32_t *us = lds + POLR_RES_HOT_DWORDS + 12;
-	OffsCache oc;
-	oc.base = 0;
-	oc.n = 0;
-	oc.data = cache_lds;
-	if (cache_cap > POLR_OFFS_CACHE) {
-		cache_cap = POLR_OFFS_CACHE;
-	}
-	if (reset) {
-		// a fresh MultiplexerState (what polr_mpx_reset does between passes), without a launch of its own
-		for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
-			mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = 0;
-		}
-		if (lane == 0) {
-			const polr_mpx_config cfg = m->cfg;
-			m->core.Init(cfg.routing, m->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
-			m->num_intermediates_total = 0;
-			m->num_rounds = 0;
-			m->n_log = 0;
-			m->last_path = 0;
-		}
-	}
-	if (lane == 0) {
-		// what polr_mpx_set_range_kernel does for a per-round run
-		m->chunk_idx = x.morsel_cursor ? 0 : x.chunk_begin;
-		m->chunk_end = x.morsel_cursor ? 0 : x.chunk_end;
-		m->chunk_offsets = x.chunk_offsets;
-		m->n_chunks = x.n_chunks;
-		m->n_tuples = x.n_tuples;
-		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
-	}
-	const size_t bank_stride = (size_t)POLR_NSHARD * POLR_KMAX;
-	__builtin_amdgcn_wave_barrier();
-	unsigned long long target[2];
-	if (((volatile DevMpx *)m)->res_valid) {
-		target[0] = ((volatile DevMpx *)m)->res_target[0];
-		target[1] = ((volatile DevMpx *)m)->res_target[1];
-	} else {
-		// first resident run of this multiplexer, or the previous one was given up: read the arrival counters and
-		// drop whatever the second counter bank still holds (the first is dropped / absorbed by the first step)
-		target[0] = polr_res_arrived(x.sync, 0, lane);
-		target[1] = polr_res_arrived(x.sync, 1, lane);
-		polr_router_step_absorb(m, mg, x.counts + bank_stride, k, lane, true, true);
-	}
-	uint32_t round_no = 0;
-	uint32_t n_steps = 0;
-	uint32_t n_pub = 0;          // rounds published so far: the next one goes to slot n_pub & 1
-	bool have_pending = false;   // a published round whose counters have not been absorbed yet ...
-	uint32_t pend_slot = 0;      // ... in this slot
-	bool have_spec = false;      // the round after it is published too (speculated), descriptor kept for the check
-	unsigned long long spec_bw = 0;
-	uint32_t spec_count = 0, spec_blocks = 0;
-	bool failed = false;
-	while (true) {
-		__builtin_amdgcn_wave_barrier();
-		if (lane == 0) {
-			RES_STAMP(x, n_steps, 0)
-		}
-		// (1) the oldest round in flight has to be complete before its counters can be absorbed
-		if (have_pending) {
-			const unsigned long long t0 = wall_clock64();
-			while (polr_res_arrived(x.sync, pend_slot, lane) != target[pend_slot]) {
-				__builtin_amdgcn_s_sleep(1);
-				if (wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
-					failed = true; // a worker is missing
-					break;
-				}
-			}
-			if (lane == 0) {
-				RES_STAMP(x, n_steps, 2)
-			}
-			if (failed) {
-				break;
-			}
-		}
-		// (2) the real step.  The round it routes is dealt to the worker workgroups that have started by now
-		// (at least one) -- or to those its speculated twin was dealt to
-		uint32_t n_blocks = spec_blocks;
-		if (!have_spec) {
-			const unsigned long long t0 = wall_clock64();
-			n_blocks = n_steps == 0 ? reg_early : 0u; // (first step: the value requested at entry)
-			while (n_blocks == 0) {
-				n_blocks = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (n_blocks != 0 || wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
-					break;
-				}
-				__builtin_amdgcn_s_sleep(2);
-			}
-			n_blocks = __shfl(n_blocks, 0, 64);
-			n_blocks = n_blocks > 4095u ? 4095u : n_blocks;
-			if (n_blocks == 0) {
-				failed = true; // not one worker workgroup got onto the device in 4 s
-				break;
-			}
-		}
-		// (a reset run drops whatever the counters still hold: first step only)
-		if (!(reset && n_steps == 0)) { // (a reset run starts on the bank it dropped at entry)
-			const uint64_t got = polr_router_step_absorb(m, mg, x.counts + (have_pending ? pend_slot : 0u) * bank_stride,
-			                                             k, lane, true, false);
-			if (lane == 0) {
-				m->core.AddNumIntermediates(got);
-				m->num_intermediates_total += got;
-			}
-		}
-		if (lane == 0 && x.morsel_cursor && m->chunk_idx >= m->chunk_end) {
-			// this executor's morsel is used up (or it has none yet): pull the next one
-			const unsigned long long next = atomicAdd(x.morsel_cursor, (unsigned long long)x.morsel_chunks);
-			if (next < x.morsel_end) {
-				m->chunk_idx = next;
-				m->chunk_end = next + x.morsel_chunks < x.morsel_end ? next + x.morsel_chunks : x.morsel_end;
-				m->done = 0;
-			}
-		}
-		n_steps++;
-		// Two passes over ONE inlined copy of the routing code (two call sites would double the router's register
-		// pressure): pass 0 is the real step on the state, pass 1 -- only if the decision after it cannot depend
-		// on the intermediates of the round just routed -- rehearses the next step on a copy and publishes it in
-		// the other slot.
-		bool stop = false;
-		for (uint32_t pass = 0; pass < 2 && !stop; pass++) {
-			__builtin_amdgcn_wave_barrier();
-			if (pass == 1) {
-				if (have_spec || !polr_can_speculate(((volatile DevMpx *)m)->core)) {
-					break;
-				}
-				// the rehearsal runs IN PLACE (the routing code then only ever sees the one LDS object, which keeps
-				// its accesses LDS instructions); the state is saved here and put back below
-				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
-					scratch_lds[i] = lds[i];
-				}
-				__builtin_amdgcn_wave_barrier();
-				if (lane == 0) {
-					m->log_enabled = 0; // (no trace of the rehearsal)
-				}
-			}
-			if (lane == 0) {
-				polr_router_route(m, round, prefix, us, n_blocks * wpb, &oc);
-			}
-			__builtin_amdgcn_wave_barrier();
-			if (pass == 0 && !have_spec && n_blocks < expected_blocks && ((volatile DevMpx *)m)->done == 0 &&
-			    ((volatile DevRound *)round)->count > (uint64_t)n_blocks * wpb * 64u) {
-				// The round is bigger than one step of the workgroups registered so far, and it may be the only one
-				// (DEFAULT_PATH): the workgroups of a launch start within a few microseconds of each other, so
-				// give the stragglers that long, then size the units for whoever is there (a device shared with
-				// other kernels: the registered ones do the work).
-				const unsigned long long t1 = wall_clock64();
-				uint32_t nb = n_blocks;
-				while (nb < expected_blocks && wall_clock64() - t1 < 500ull /* 5 us */) {
-					__builtin_amdgcn_s_sleep(1);
-					nb = __hip_atomic_load(registered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				nb = __shfl(nb, 0, 64);
-				n_blocks = nb > 4095u ? 4095u : nb;
-				if (lane == 0) {
-					polr_size_units(round->count, n_blocks * wpb, 64, us, prefix);
-				}
-				__builtin_amdgcn_wave_barrier();
-			}
-			// (all lanes read what lane 0 left in LDS)
-			DevMpx *tgt = m;
-			DevRound *rd = round;
-			uint64_t *pf = prefix;
-			uint32_t *uu = us;
-			const bool done = ((volatile DevMpx *)tgt)->done != 0;
-			const volatile DevRound *vr = rd;
-			const unsigned long long bw_base = (unsigned long long)(uint32_t)vr->begin |
-			                                   ((unsigned long long)((((volatile uint32_t *)uu)[0] >> 6) & 63u) << 32) |
-			                                   ((unsigned long long)(vr->path & 31u) << 38) |
-			                                   ((unsigned long long)(vr->emit & 1u) << 43) |
-			                                   ((unsigned long long)(n_blocks & 0xFFFu) << 44);
-			const uint32_t cnt = (uint32_t)vr->count;
-			const uint64_t n_units_routed = ((volatile uint64_t *)pf)[1];
-			if (pass == 1) {
-				__builtin_amdgcn_wave_barrier();
-				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
-					lds[i] = scratch_lds[i];
-				}
-				__builtin_amdgcn_wave_barrier();
-			}
-			if (pass == 0 && have_spec) {
-				// this round is already out: the real decision must be the speculated one, bit for bit
-				if (done || bw_base != spec_bw || cnt != spec_count) {
-					failed = true; // (cannot happen while polr_can_speculate is right; never continue on a wrong round)
-					stop = true;
-					break;
-				}
-				have_spec = false;
-				pend_slot ^= 1u;
-				continue;
-			}
-			if (done) {
-				if (pass == 0) {
-					round_no = polr_res_next_round(round_no);
-					__hip_atomic_store(&x.sync->pub[lane].a[n_pub & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
-					                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					stop = true;
-				}
-				break; // (a rehearsal that runs off the end of the source publishes nothing)
-			}
-			round_no = polr_res_next_round(round_no);
-			const uint32_t slot = n_pub & 1u;
-			__hip_atomic_store(&x.sync->pub[lane].b[slot],
-			                   bw_base | ((unsigned long long)polr_res_tag(x.epoch, round_no) << 56), __ATOMIC_RELAXED,
-			                   __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(&x.sync->pub[lane].a[slot], polr_res_word_a(x.epoch, round_no, cnt), __ATOMIC_RELAXED,
-			                   __HIP_MEMORY_SCOPE_AGENT);
-			target[slot] += n_units_routed;
-			n_pub++;
-			if (pass == 0) {
-				pend_slot = slot;
-				have_pending = true;
-				if (lane == 0) {
-					RES_STAMP(x, n_steps - 1, 1)
-				}
-			} else {
-				have_spec = true;
-				spec_bw = bw_base;
-				spec_count = cnt;
-				spec_blocks = n_blocks;
-			}
-		}
-		if (stop) {
-			break;
-		}
-		// while the workers probe: keep the boundaries of the chunks ahead in LDS
-		{
-			const uint64_t ci = ((volatile DevMpx *)m)->chunk_idx;
-			if (x.chunk_offsets && ci - oc.base >= oc.n / 2) { // (also the first fill: n == 0)
-				polr_offs_cache_fill(oc, x, ci, cache_cap, lane);
-			}
-		}
-	}
-	if (failed) {
-		// release everybody (in both slots) and report (host: progress word 2)
-		round_no = polr_res_next_round(round_no);
-		__hip_atomic_store(&x.sync->pub[lane].a[n_pub & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
-		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		round_no = polr_res_next_round(round_no);
-		__hip_atomic_store(&x.sync->pub[lane].a[(n_pub + 1) & 1u], polr_res_word_a(x.epoch, round_no, POLR_RES_DONE),
-		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (lane == 0 && host_words) {
-			host_words[2] = 1;
-		}
-	}
-	__builtin_amdgcn_wave_barrier();
-	if (x.flags & POLR_RUN_FINISH) {
-		if (lane == 0) {
-			polr_close_run(m);
-		}
-		__builtin_amdgcn_wave_barrier();
-		polr_write_stats(m, mg, x.stats_out, lane);
-	}
-	__builtin_amdgcn_wave_barrier();
-	if (lane == 0) {
-		m->res_valid = failed ? 0u : 1u;
-		m->res_target[0] = target[0];
-		m->res_target[1] = target[1];
-		m->progress = host_words;
-		if (host_words) { // what a per-round run would have published: the run is over
-			host_words[1] = m->done;
-			host_words[0] = m->steps_done;
-		}
-	}
-	__builtin_amdgcn_wave_barrier();
-	{
-		uint32_t *dst = (uint32_t *)mg;
-		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
-			dst[i] = lds[i];
-		}
-	}
-	if (lane == 0) {
-		RES_STAMP(x, 0, 6)
 	}
 }

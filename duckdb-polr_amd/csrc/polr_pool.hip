@@ -59,12 +59,9 @@ __device__ __forceinline__ void pool_load_exec(const ResidentExec *xp, ResidentE
 	x.chunk_offsets = (const uint64_t *)uni64((uint64_t)xp->chunk_offsets);
 	x.n_chunks = uni64(xp->n_chunks);
 	x.n_tuples = uni64(xp->n_tuples);
-	x.epoch = uni(xp->epoch);
 	x.flags = uni(xp->flags);
-	x.registered = 0;
 	x.pad = 0;
 	x.stats_out = (polr_mpx_stats *)uni64((uint64_t)xp->stats_out);
-	x.stamps = nullptr;
 	x.morsel_cursor = (unsigned long long *)uni64((uint64_t)xp->morsel_cursor);
 	x.morsel_end = uni64(xp->morsel_end);
 	x.morsel_chunks = uni(xp->morsel_chunks);

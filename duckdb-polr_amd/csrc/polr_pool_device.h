@@ -99,8 +99,8 @@ __device__ __forceinline__ uint32_t polr_pool_tag(unsigned long long ticket, uin
 __device__ __forceinline__ unsigned long long polr_pool_g0(uint32_t tag, uint32_t kind, uint32_t slot, uint32_t emit,
                                                            uint32_t path, uint32_t begin) {
 	return ((unsigned long long)tag << 48) | ((unsigned long long)(kind & 3u) << 46) |
-	       ((unsigned long long)(slot & 1u) << 45) | ((unsigned long long)(emit & 1u) << 44) |
-	       ((unsigned long long)(path & 31u) << 39) | begin;
+	       ((unsigned long long)(slot & 3u) << 44) | ((unsigned long long)(emit & 1u) << 43) |
+	       ((unsigned long long)(path & 31u) << 38) | begin;
 }
 __device__ __forceinline__ unsigned long long polr_pool_g1(uint32_t tag, uint32_t exec, uint32_t count) {
 	return ((unsigned long long)tag << 48) | ((unsigned long long)(exec & 0xFFFFu) << 32) | count;
@@ -247,9 +247,9 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 		return false;
 	}
 	u.kind = (uint32_t)(g0 >> 46) & 3u;
-	u.slot = (uint32_t)(g0 >> 45) & 1u;
-	u.emit = (uint32_t)(g0 >> 44) & 1u;
-	u.path = (uint32_t)(g0 >> 39) & 31u;
+	u.slot = (uint32_t)(g0 >> 44) & 3u;
+	u.emit = (uint32_t)(g0 >> 43) & 1u;
+	u.path = (uint32_t)(g0 >> 38) & 31u;
 	u.begin = (uint32_t)g0;
 	u.exec = (uint32_t)(g1 >> 32) & 0xFFFFu;
 	u.count = (uint32_t)g1;
@@ -439,30 +439,98 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
 	}
 	__builtin_amdgcn_wave_barrier();
-	unsigned long long target[2];
+	unsigned long long target[POLR_SLOTS];
 	if (((volatile DevMpx *)m)->res_valid) {
-		target[0] = ((volatile DevMpx *)m)->res_target[0];
-		target[1] = ((volatile DevMpx *)m)->res_target[1];
+#pragma unroll
+		for (uint32_t s = 0; s < POLR_SLOTS; s++) {
+			target[s] = ((volatile DevMpx *)m)->res_target[s];
+		}
 	} else {
-		target[0] = polr_pool_arrived(x.sync, 0, lane);
-		target[1] = polr_pool_arrived(x.sync, 1, lane);
-		polr_pool_absorb(m, mg, x.counts + bank_stride, k, lane, true);
+#pragma unroll
+		for (uint32_t s = 0; s < POLR_SLOTS; s++) {
+			target[s] = polr_pool_arrived(x.sync, s, lane);
+			if (s) {
+				polr_pool_absorb(m, mg, x.counts + s * bank_stride, k, lane, true);
+			}
+		}
 	}
+	// Rounds in flight, oldest first: the FRONT one is decided (the state has routed it); the ones behind it were
+	// rehearsed ahead on a copy of the state (the shadow) and published already -- every real step that follows must
+	// decide exactly them, in order.  Round i of the run sits in slot i % POLR_SLOTS, so the front's slot is
+	// (n_pub - n_fly) % POLR_SLOTS.
 	uint32_t n_steps = 0;
-	uint32_t n_pub = 0;        // rounds published so far: the next one goes to slot n_pub & 1
-	bool have_pending = false; // a published round whose counters have not been absorbed yet ...
-	uint32_t pend_slot = 0;    // ... in this slot
-	bool have_spec = false;    // the round after it is published too (speculated), kept for the check
-	PoolRoundOut spec = {};
+	uint32_t n_pub = 0; // rounds published so far
+	uint32_t n_fly = 0; // published, counters not absorbed yet
+	PoolRoundOut ahead[POLR_SLOTS - 1] = {}; // the rehearsed rounds behind the front (statically indexed: registers)
+	bool shadow_valid = false;               // scratch_lds holds the state as it will be after the last rehearsed round
+	bool shadow_ended = false;               // the rehearsal ran off the end of the source: nothing more to publish ahead
 	bool failed = false;
 	uint32_t rot = exec; // units of consecutive rounds start on different rings
+	// one routing step on whatever state sits in `lds` (the real one, or the shadow swapped in): the round it decides
+	auto route_here = [&](PoolRoundOut &r) -> bool {
+		if (lane == 0) {
+			polr_router_route(m, round, prefix, us, rh.pool_waves, &oc);
+			if (x.path_plus1) {
+				// BACKPRESSURE (src/parallel/pipeline.cpp:147-156, polar_config.cpp:128-147): this executor IS one
+				// join order; its multiplexer routes DEFAULT_PATH, the order it stands for replaces path 0
+				round->path = x.path_plus1 - 1u;
+				m->last_path = x.path_plus1 - 1u;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		const bool done = ((volatile DevMpx *)m)->done != 0;
+		const volatile DevRound *vr = round;
+		r.begin = (uint32_t)vr->begin;
+		r.count = (uint32_t)vr->count;
+		r.path = vr->path;
+		r.emit = vr->emit;
+		// a round is cut for the executors that are still routing: the last ones get the whole pool
+		uint32_t active = rh.n_exec;
+		if (r.count > rh.hi_tuples) {
+			// (routers_done counts executors that have finished ROUTING; their terminal rounds may still
+			// be queued, which is what the lo queue is for)
+			const uint32_t done_now = __hip_atomic_load(&run->routers_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			active = done_now < rh.n_exec ? rh.n_exec - done_now : 1u;
+		}
+		const bool terminal = ((volatile DevMpx *)m)->core.num_cache_flushing_skips == polr::kIdxMax;
+		polr_pool_size_units(r.count, rh.pool_waves, active, gran, rh.hi_tuples, rh.units_x, rh.hi_unit, terminal, r);
+		return done;
+	};
+	auto publish = [&](const PoolRoundOut &r) {
+		const uint32_t slot = n_pub & (POLR_SLOTS - 1u);
+		polr_pool_publish(rh, sync, exec, slot, r, rot, lane);
+		rot += r.n_units;
+#pragma unroll
+		for (uint32_t s = 0; s < POLR_SLOTS; s++) {
+			if (s == slot) {
+				target[s] += r.n_units;
+			}
+		}
+		n_pub++;
+		n_fly++;
+	};
+	auto swap_shadow = [&]() {
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
+			const uint32_t a = lds[i], b = scratch_lds[i];
+			lds[i] = b;
+			scratch_lds[i] = a;
+		}
+		__builtin_amdgcn_wave_barrier();
+	};
 	while (true) {
 		__builtin_amdgcn_wave_barrier();
+		const uint32_t front_slot = (n_pub - n_fly) & (POLR_SLOTS - 1u);
 		// (1) the oldest round in flight has to be complete before its counters can be absorbed
-		if (have_pending) {
+		if (n_fly) {
+			unsigned long long want = 0;
+#pragma unroll
+			for (uint32_t s = 0; s < POLR_SLOTS; s++) {
+				want = s == front_slot ? target[s] : want;
+			}
 			const unsigned long long t0 = wall_clock64();
 			uint32_t spins = 0;
-			while (polr_pool_arrived(x.sync, pend_slot, lane) != target[pend_slot]) {
+			while (polr_pool_arrived(x.sync, front_slot, lane) != want) {
 				__builtin_amdgcn_s_sleep(1);
 				if ((++spins & 63u) == 0) {
 					uint32_t ab = __hip_atomic_load(&run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -478,8 +546,7 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		}
 		// (2) the real step
 		if (!(reset && n_steps == 0)) { // (a reset run starts on the bank it dropped at entry)
-			const uint64_t got =
-			    polr_pool_absorb(m, mg, x.counts + (have_pending ? pend_slot : 0u) * bank_stride, k, lane, false);
+			const uint64_t got = polr_pool_absorb(m, mg, x.counts + (n_fly ? front_slot : 0u) * bank_stride, k, lane, false);
 			if (lane == 0) {
 				m->core.AddNumIntermediates(got);
 				m->num_intermediates_total += got;
@@ -495,90 +562,68 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			}
 		}
 		n_steps++;
-		// Two passes over ONE inlined copy of the routing code: pass 0 is the real step on the state, pass 1 -- only
-		// if the decision after it cannot depend on the intermediates of the round just routed -- rehearses the
-		// next step on a copy and publishes it in the other slot.
-		bool stop = false;
-		for (uint32_t pass = 0; pass < 2 && !stop; pass++) {
-			__builtin_amdgcn_wave_barrier();
-			if (pass == 1) {
-				if (have_spec || !polr_can_speculate(((volatile DevMpx *)m)->core)) {
+		__builtin_amdgcn_wave_barrier();
+		{
+			PoolRoundOut r;
+			const bool done = route_here(r);
+			if (n_fly > 1) {
+				// this round is already out: the real decision must be the rehearsed one, bit for bit
+				const PoolRoundOut &sp = ahead[0];
+				if (done || r.begin != sp.begin || r.count != sp.count || r.path != sp.path || r.emit != sp.emit) {
+					failed = true; // (cannot happen while polr_can_speculate is right; never continue on a wrong round)
 					break;
 				}
+#pragma unroll
+				for (uint32_t i = 0; i + 1 < POLR_SLOTS - 1; i++) {
+					ahead[i] = ahead[i + 1];
+				}
+				n_fly--;
+			} else {
+				n_fly = 0;
+				if (done) {
+					break;
+				}
+				publish(r);
+				shadow_valid = false;
+				shadow_ended = false;
+			}
+		}
+		// (3) rehearse ahead: while the decision after the last published round cannot depend on intermediates that
+		// are still outstanding, decide it on the shadow and publish it in the next slot
+		while (n_fly < POLR_SLOTS && !shadow_ended) {
+			if (!shadow_valid) {
+				if (!polr_can_speculate(((volatile DevMpx *)m)->core)) {
+					break;
+				}
+				__builtin_amdgcn_wave_barrier();
 				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
 					scratch_lds[i] = lds[i];
 				}
 				__builtin_amdgcn_wave_barrier();
 				if (lane == 0) {
-					m->log_enabled = 0; // (no trace of the rehearsal)
+					((DevMpx *)scratch_lds)->log_enabled = 0; // (no trace of a rehearsal)
+				}
+				shadow_valid = true;
+			} else if (!polr_can_speculate(((volatile DevMpx *)scratch_lds)->core)) {
+				break;
+			}
+			// the rehearsal runs IN PLACE (the routing code only ever sees the one LDS object, which keeps its accesses
+			// LDS instructions): the shadow is swapped in, routed, and swapped out again
+			swap_shadow();
+			PoolRoundOut r2;
+			const bool done2 = route_here(r2);
+			swap_shadow();
+			if (done2) {
+				shadow_ended = true; // (a rehearsal that runs off the end of the source publishes nothing)
+				break;
+			}
+#pragma unroll
+			for (uint32_t i = 0; i < POLR_SLOTS - 1; i++) {
+				if (i + 1 == n_fly) {
+					ahead[i] = r2;
 				}
 			}
-			if (lane == 0) {
-				polr_router_route(m, round, prefix, us, rh.pool_waves, &oc);
-				if (x.path_plus1) {
-					// BACKPRESSURE (src/parallel/pipeline.cpp:147-156, polar_config.cpp:128-147): this executor IS one
-					// join order; its multiplexer routes DEFAULT_PATH, the order it stands for replaces path 0
-					round->path = x.path_plus1 - 1u;
-					m->last_path = x.path_plus1 - 1u;
-				}
-			}
-			__builtin_amdgcn_wave_barrier();
-			const bool done = ((volatile DevMpx *)m)->done != 0;
-			const volatile DevRound *vr = round;
-			PoolRoundOut r;
-			r.begin = (uint32_t)vr->begin;
-			r.count = (uint32_t)vr->count;
-			r.path = vr->path;
-			r.emit = vr->emit;
-			// a round is cut for the executors that are still routing: the last ones get the whole pool
-			uint32_t active = rh.n_exec;
-			if (r.count > rh.hi_tuples) {
-				// (routers_done counts executors that have finished ROUTING; their terminal rounds may still
-				// be queued, which is what the lo queue is for)
-				const uint32_t done_now = __hip_atomic_load(&run->routers_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				active = done_now < rh.n_exec ? rh.n_exec - done_now : 1u;
-			}
-			const bool terminal = ((volatile DevMpx *)m)->core.num_cache_flushing_skips == polr::kIdxMax;
-			polr_pool_size_units(r.count, rh.pool_waves, active, gran, rh.hi_tuples, rh.units_x, rh.hi_unit, terminal, r);
-			if (pass == 1) {
-				__builtin_amdgcn_wave_barrier();
-				for (uint32_t i = lane; i < POLR_RES_HOT_DWORDS; i += 64) {
-					lds[i] = scratch_lds[i];
-				}
-				__builtin_amdgcn_wave_barrier();
-			}
-			if (pass == 0 && have_spec) {
-				// this round is already out: the real decision must be the speculated one, bit for bit
-				if (done || r.begin != spec.begin || r.count != spec.count || r.path != spec.path || r.emit != spec.emit) {
-					failed = true; // (cannot happen while polr_can_speculate is right; never continue on a wrong round)
-					stop = true;
-					break;
-				}
-				have_spec = false;
-				pend_slot ^= 1u;
-				continue;
-			}
-			if (done) {
-				if (pass == 0) {
-					stop = true;
-				}
-				break; // (a rehearsal that runs off the end of the source publishes nothing)
-			}
-			const uint32_t slot = n_pub & 1u;
-			polr_pool_publish(rh, sync, exec, slot, r, rot, lane);
-			rot += r.n_units;
-			target[slot] += r.n_units;
-			n_pub++;
-			if (pass == 0) {
-				pend_slot = slot;
-				have_pending = true;
-			} else {
-				have_spec = true;
-				spec = r;
-			}
-		}
-		if (stop) {
-			break;
+			publish(r2);
 		}
 		// while the pool probes: keep the boundaries of the chunks ahead in LDS
 		{
@@ -607,8 +652,10 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	__builtin_amdgcn_wave_barrier();
 	if (lane == 0) {
 		m->res_valid = failed ? 0u : 1u;
-		m->res_target[0] = target[0];
-		m->res_target[1] = target[1];
+#pragma unroll
+		for (uint32_t s = 0; s < POLR_SLOTS; s++) {
+			m->res_target[s] = target[s];
+		}
 		m->progress = host_words;
 		if (host_words) { // what a per-round run would have published: the run is over
 			host_words[1] = m->done;

@@ -622,13 +622,23 @@ def run_backpressure(mpxs, chunk_begin, chunk_end, morsel_chunks=120, out=None, 
                                               (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0)))
 
 
-def finish_many(mpxs):
+def finish_many_raw(mpxs):
+    """polr_mpx_finish_many: settles the run(s) of these multiplexers and returns their statistics as the C structs
+    (stats_dicts() turns them into dictionaries -- host-side bookkeeping a measurement keeps outside its clock)"""
     n = len(mpxs)
     hs = (C.c_void_p * n)(*[m.h for m in mpxs])
     stats = (MpxStats * n)()
     ctx = mpxs[0].ctx
     ctx.check(ctx.L.polr_mpx_finish_many(hs, n, stats))
-    return [_stats_dict(stats[i], mpxs[i].pipe.n_paths, mpxs[i].pipe.k) for i in range(n)]
+    return stats
+
+
+def stats_dicts(stats, mpxs):
+    return [_stats_dict(stats[i], mpxs[i].pipe.n_paths, mpxs[i].pipe.k) for i in range(len(mpxs))]
+
+
+def finish_many(mpxs):
+    return stats_dicts(finish_many_raw(mpxs), mpxs)
 
 
 COMM_ID_BYTES = 128
