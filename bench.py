@@ -332,7 +332,10 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     budget = args.regret_budget
     if routing == "exponential_backoff":
         budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
-    want_e = args.executors if args.executors > 0 else (256 if n_chunks > 65536 else 32)
+    # executors: 256 for table-sized sources; 32 for small ones -- except the strategies that decide every chunk
+    # (one dependent routing round trip per chunk and executor: they want as many executors as the grid carries)
+    per_chunk = routing in ("opportunistic", "dynamic")
+    want_e = args.executors if args.executors > 0 else (256 if n_chunks > 65536 else (640 if per_chunk else 32))
     E = max(1, min(want_e, n_chunks))
     P = max(1, args.streams) if not args.sync_every_step else 1
     sets = []

@@ -17,6 +17,29 @@
 
 #include <stdint.h>
 
+// Device code names the address space of what it loads from: a pointer rebuilt from an integer (descriptors travel as
+// 64-bit words through LDS and scalar registers) is a GENERIC pointer to the compiler, and a generic access is a FLAT
+// instruction -- it counts against the LDS counter (lgkmcnt) as well as the memory counter, so every wait for an LDS
+// read would also wait for all key-column loads in flight.  as_global()/as_lds() give GLOBAL_/DS_ instructions.
+#if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
+#define POLR_GLOBAL __attribute__((address_space(1)))
+#define POLR_LDS __attribute__((address_space(3)))
+template <class T>
+__device__ __forceinline__ POLR_GLOBAL T *as_global(T *p) {
+	return (POLR_GLOBAL T *)p;
+}
+template <class T>
+__device__ __forceinline__ POLR_LDS T *as_lds(T *p) {
+	return (POLR_LDS T *)p;
+}
+// one 16-byte load from global memory (the HIP vector classes do not bind to address-space qualified references)
+typedef uint32_t polr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_global_x4(const POLR_GLOBAL uint32_t *p) {
+	const polr_u32x4 v = *(const POLR_GLOBAL polr_u32x4 *)p;
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
+
 #define POLR_KMAX 8
 #define POLR_PMAX 32
 #define POLR_WMAX (1 + POLR_KMAX)

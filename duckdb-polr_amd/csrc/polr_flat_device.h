@@ -55,9 +55,9 @@ __device__ __host__ constexpr int flat_per_wave_dwords() {
 
 // scalar view of one stage (SGPRs; loaded from the StageDesc array in global memory through the scalar cache)
 struct FlatStage {
-	const uint32_t *keys;
-	const uint8_t *valid;
-	const uint32_t *table; // bit words or {key,row} slots in HBM
+	const POLR_GLOBAL uint32_t *keys;
+	const POLR_GLOBAL uint8_t *valid;
+	const POLR_GLOBAL uint32_t *table; // bit words or {key,row} slots in HBM
 	uint32_t kind_lds;     // kind | lds_off1 << 8 (lds_off1: 1 + dword offset inside the workgroup's LDS table area, 0 = HBM)
 	uint32_t a, b;         // perfect: min, range (32-bit modular); hash: slot mask (capacity <= 2^31), unused
 };
@@ -69,11 +69,12 @@ __device__ __forceinline__ uint64_t flat_uni64(uint64_t v) {
 	return ((uint64_t)flat_uni((uint32_t)(v >> 32)) << 32) | flat_uni((uint32_t)v);
 }
 
-__device__ __forceinline__ FlatStage flat_load_stage(const StageDesc *d) {
+__device__ __forceinline__ FlatStage flat_load_stage(const StageDesc *d_generic) {
+	const POLR_GLOBAL StageDesc *d = as_global(d_generic);
 	FlatStage s;
-	s.keys = (const uint32_t *)flat_uni64((uint64_t)d->key_data[0]);
-	s.valid = (const uint8_t *)flat_uni64((uint64_t)d->key_valid[0]);
-	s.table = (const uint32_t *)flat_uni64((uint64_t)d->table);
+	s.keys = as_global((const uint32_t *)flat_uni64((uint64_t)d->key_data[0]));
+	s.valid = as_global((const uint8_t *)flat_uni64((uint64_t)d->key_valid[0]));
+	s.table = as_global((const uint32_t *)flat_uni64((uint64_t)d->table));
 	const uint32_t kind = flat_uni(d->kind);
 	s.kind_lds = kind | (flat_uni(d->lds_off1) << 8);
 	s.a = kind == KIND_PERFECT ? flat_uni((uint32_t)d->min_value) : flat_uni((uint32_t)d->mask);
@@ -85,9 +86,9 @@ template <int K>
 struct FlatCtx {
 	uint32_t k, lane;
 	FlatStage st[K]; // the current join order, statically indexed (SGPRs)
-	const uint32_t *sel;
-	const uint32_t *lds_tables; // the workgroup's LDS-resident bit tables
-	uint16_t *q;                // this wave's queues
+	const POLR_GLOBAL uint32_t *sel;
+	const POLR_LDS uint32_t *lds_tables; // the workgroup's LDS-resident bit tables
+	POLR_LDS uint16_t *q;                // this wave's queues
 	uint32_t qsize[K], cnt[K];
 	uint64_t unit_begin, in_pos, in_end;
 	// stage 0's next step, requested one step ahead (the key stream's HBM round trip overlaps the current step)
@@ -103,7 +104,7 @@ __device__ __forceinline__ uint32_t flat_rank(uint64_t m) {
 // perfect table: 32-bit modular arithmetic, exact for signed and unsigned 4-byte keys while [min, max] lies inside the
 // key type's domain (checked on the host).  w = the loaded bit word (0 where the key is out of range / inactive).
 template <int F>
-__device__ __forceinline__ void flat_perfect_issue(const FlatStage &s, const uint32_t *lds_tables, const uint32_t (&key)[F],
+__device__ __forceinline__ void flat_perfect_issue(const FlatStage &s, const POLR_LDS uint32_t *lds_tables, const uint32_t (&key)[F],
                                                    const bool (&act)[F], uint32_t (&idx)[F], uint32_t (&w)[F]) {
 	const uint32_t lds_off1 = s.kind_lds >> 8;
 	bool in[F];
@@ -114,7 +115,7 @@ __device__ __forceinline__ void flat_perfect_issue(const FlatStage &s, const uin
 		w[i] = 0;
 	}
 	if (lds_off1) {
-		const uint32_t *bits = lds_tables + (lds_off1 - 1u);
+		const POLR_LDS uint32_t *bits = lds_tables + (lds_off1 - 1u);
 #pragma unroll
 		for (int i = 0; i < F; i++) {
 			if (in[i]) {
@@ -136,7 +137,7 @@ __device__ __forceinline__ void flat_perfect_issue(const FlatStage &s, const uin
 template <int F>
 __device__ __forceinline__ void flat_hash_lookup(const FlatStage &s, const uint32_t (&key)[F], const bool (&act)[F],
                                                  bool (&hit)[F]) {
-	const uint4 *tab = (const uint4 *)s.table;
+	const POLR_GLOBAL uint32_t *tab = s.table; // (groups of 8 dwords)
 #pragma unroll
 	for (int h0 = 0; h0 < F; h0 += 4) {
 		uint32_t group[4], first[4];
@@ -157,8 +158,8 @@ __device__ __forceinline__ void flat_hash_lookup(const FlatStage &s, const uint3
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				if (searching[i]) {
-					a[i] = tab[(uint64_t)group[i] * 2];
-					b[i] = tab[(uint64_t)group[i] * 2 + 1];
+					a[i] = load_global_x4(tab + (uint64_t)group[i] * 8);
+					b[i] = load_global_x4(tab + (uint64_t)group[i] * 8 + 4);
 				}
 			}
 			any = false;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void flat_hash_lookup(const FlatStage &s, const uint3
 }
 
 template <int F>
-__device__ __forceinline__ void flat_lookup(const FlatStage &s, const uint32_t *lds_tables, const uint32_t (&key)[F],
+__device__ __forceinline__ void flat_lookup(const FlatStage &s, const POLR_LDS uint32_t *lds_tables, const uint32_t (&key)[F],
                                             const bool (&act)[F], bool (&hit)[F]) {
 	if ((s.kind_lds & 0xFFu) == KIND_PERFECT) {
 		uint32_t idx[F], w[F];
@@ -208,7 +209,7 @@ __device__ __forceinline__ void flat_emit(FlatCtx<K> &c, const uint32_t (&pos)[F
 	const bool last = POS + 1 >= K || POS + 1 == (int)c.k;
 	uint32_t total = 0;
 	if constexpr (POS + 1 < K) {
-		uint16_t *qq = c.q + flat_qoff<K>(POS + 1);
+		POLR_LDS uint16_t *qq = c.q + flat_qoff<K>(POS + 1);
 		uint32_t qs = c.qsize[POS + 1];
 #pragma unroll
 		for (int i = 0; i < F; i++) {
@@ -250,12 +251,12 @@ __device__ __forceinline__ void flat_stage0(FlatCtx<K> &c) {
 			kk[0] = c.pf0;
 			kk[1] = c.pf1;
 		} else {
-			kk[0] = *(const uint4 *)(s.keys + base);
-			kk[1] = *(const uint4 *)(s.keys + base + 256u);
+			kk[0] = load_global_x4(s.keys + base);
+			kk[1] = load_global_x4(s.keys + base + 256u);
 		}
 		if (c.in_end - c.in_pos >= 2ull * FLAT_STEP0) {
-			c.pf0 = *(const uint4 *)(s.keys + base + FLAT_STEP0);
-			c.pf1 = *(const uint4 *)(s.keys + base + FLAT_STEP0 + 256u);
+			c.pf0 = load_global_x4(s.keys + base + FLAT_STEP0);
+			c.pf1 = load_global_x4(s.keys + base + FLAT_STEP0 + 256u);
 			c.pf_pos = c.in_pos + FLAT_STEP0;
 		} else {
 			c.pf_pos = ~0ull;
@@ -340,7 +341,7 @@ __device__ __forceinline__ void flat_sweep(FlatCtx<K> &c) {
 				const uint32_t qs = c.qsize[p];
 				const uint32_t n = qs < (uint32_t)(64 * F) ? qs : (uint32_t)(64 * F);
 				const uint32_t base = qs - n;
-				const uint16_t *qq = c.q + flat_qoff<K>(p);
+				const POLR_LDS uint16_t *qq = c.q + flat_qoff<K>(p);
 				uint32_t row[F];
 #pragma unroll
 				for (int i = 0; i < F; i++) {
@@ -379,17 +380,34 @@ __device__ __forceinline__ void flat_sweep(FlatCtx<K> &c) {
 			if (p < (int)c.k && (c.st[p].kind_lds & 0xFFu) == KIND_PERFECT) {
 				const FlatStage &s = c.st[p];
 				const uint32_t lds_off1 = s.kind_lds >> 8;
-				const uint32_t *bits = lds_off1 ? c.lds_tables + (lds_off1 - 1u) : s.table;
+				bool in[F];
 #pragma unroll
 				for (int i = 0; i < F; i++) {
 					const uint32_t idx = key[p - 1][i] - s.a;
-					const bool in = pos[p - 1][i] != 0xFFFFFFFFu && idx <= s.b;
-					key[p - 1][i] = idx & 31u;
+					in[i] = pos[p - 1][i] != 0xFFFFFFFFu && idx <= s.b;
+					key[p - 1][i] = idx; // (the bit to test is idx & 31, taken when the word is there)
 					w[p - 1][i] = 0;
-					if (in) {
-						// (one address space per stage: LDS or global, wave-uniform)
-						w[p - 1][i] = lds_off1 ? bits[idx >> 5] : s.table[idx >> 5];
+				}
+				// (one address space per stage, wave-uniform: DS_READ or GLOBAL_LOAD, never a generic access)
+				if (lds_off1) {
+					const POLR_LDS uint32_t *bits = c.lds_tables + (lds_off1 - 1u);
+#pragma unroll
+					for (int i = 0; i < F; i++) {
+						if (in[i]) {
+							w[p - 1][i] = bits[key[p - 1][i] >> 5];
+						}
 					}
+				} else {
+#pragma unroll
+					for (int i = 0; i < F; i++) {
+						if (in[i]) {
+							w[p - 1][i] = s.table[key[p - 1][i] >> 5];
+						}
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < F; i++) {
+					key[p - 1][i] &= 31u;
 				}
 			}
 		});
@@ -424,7 +442,11 @@ __device__ __forceinline__ void flat_sweep(FlatCtx<K> &c) {
 }
 
 // run one unit [in_pos, in_end) to completion: a sweep whenever a deeper stage holds a full step, else the source; at
-// the end sweeps until every queue is empty (a unit leaves nothing behind: its counters are final when it arrives)
+// the end sweeps until every queue is empty (a unit leaves nothing behind: its counters are final when it arrives).
+// (Measured and dropped: sending a small unit, or the queue remainders at the end of a unit, down ALL remaining stages
+// at once -- two round trips instead of two per stage, but keys and table words are then loaded for tuples that are
+// already dead, and on a device whose memory system is the bottleneck that costs more than the chain it saves: SF100
+// run 1.58 -> 1.77 ms.)
 template <int K>
 __device__ __forceinline__ void flat_run_unit(FlatCtx<K> &c) {
 	while (true) {

@@ -92,17 +92,20 @@ static __device__ unsigned long long *polr_diag_tl;
 static __device__ uint32_t polr_diag_tl_cap;
 #define TL_BEGIN(first_block_)                                                                                         \
 	unsigned long long tl_wait = wall_clock64();                                                                       \
-	unsigned long long tl_got = 0;                                                                                     \
+	unsigned long long tl_got = 0, tl_run = 0;                                                                         \
 	uint32_t tl_n = 0;                                                                                                 \
 	const uint32_t tl_wave = (blockIdx.x - (first_block_)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
 #define TL_GOT tl_got = wall_clock64();
+#define TL_RUN tl_run = wall_clock64();
 #define TL_DONE(u_)                                                                                                    \
 	if (polr_diag_tl && tl_n < polr_diag_tl_cap && (threadIdx.x & 63) == 0) {                                          \
 		unsigned long long *r_ = polr_diag_tl + ((size_t)tl_wave * polr_diag_tl_cap + tl_n) * 4;                       \
 		r_[0] = tl_wait;                                                                                               \
 		r_[1] = tl_got;                                                                                                \
 		r_[2] = wall_clock64();                                                                                        \
-		r_[3] = ((unsigned long long)(u_).exec << 40) | ((unsigned long long)(u_).path << 32) | (u_).count;            \
+		const unsigned long long q_ = (tl_run - tl_got) / 25ull; /* quarter microseconds spent probing, 8 bits */      \
+		r_[3] = ((q_ > 255ull ? 255ull : q_) << 56) | ((unsigned long long)((u_).exec & 0xFFFFu) << 40) |              \
+		        ((unsigned long long)(u_).path << 32) | (u_).count;                                                    \
 	}                                                                                                                  \
 	tl_n++;                                                                                                            \
 	tl_wait = wall_clock64();
@@ -115,6 +118,7 @@ extern "C" int PASTE_TL(polr_diag_timeline_set_k, POLR_K)(unsigned long long *bu
 #else
 #define TL_BEGIN(first_block_)
 #define TL_GOT
+#define TL_RUN
 #define TL_DONE(u_)
 #endif
 
@@ -122,20 +126,22 @@ extern "C" int PASTE_TL(polr_diag_timeline_set_k, POLR_K)(unsigned long long *bu
 template <int K>
 __device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const PoolUnit &u, uint32_t ring, uint32_t k,
                                             uint32_t (&cnt)[K], uint32_t lane) {
-	const ResidentExec *xp = execs + u.exec;
-	unsigned long long *bank = (unsigned long long *)uni64((uint64_t)xp->counts) +
-	                           (size_t)u.slot * POLR_NSHARD * POLR_KMAX + (size_t)(ring & (POLR_POOL_SHARDS - 1u)) * POLR_KMAX;
-	ResidentSync *sync = (ResidentSync *)uni64((uint64_t)xp->sync);
+	const POLR_GLOBAL ResidentExec *xp = as_global(execs) + u.exec;
+	POLR_GLOBAL unsigned long long *bank = as_global((unsigned long long *)uni64((uint64_t)xp->counts)) +
+	                                       (size_t)u.slot * POLR_NSHARD * POLR_KMAX +
+	                                       (size_t)(ring & (POLR_POOL_SHARDS - 1u)) * POLR_KMAX;
+	POLR_GLOBAL ResidentSync *sync = as_global((ResidentSync *)uni64((uint64_t)xp->sync));
 	if (lane == 0) {
 		unsigned long long seen = 0;
 #pragma unroll
 		for (int p = 0; p < K; p++) {
 			if (p < (int)k && cnt[p]) {
 				// returning form: the arrival below consumes `seen`, so it is issued after the adds have been performed
-				seen |= atomicAdd(&bank[p], (unsigned long long)cnt[p]);
+				seen |= __hip_atomic_fetch_add(&bank[p], (unsigned long long)cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
-		atomicAdd(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, 1ull + (seen >> 63));
+		__hip_atomic_fetch_add(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, 1ull + (seen >> 63), __ATOMIC_RELAXED,
+		                       __HIP_MEMORY_SCOPE_AGENT);
 	}
 #pragma unroll
 	for (int p = 0; p < K; p++) {
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 		c.in_end = (uint64_t)u.begin + u.count;
 		run_until_idle(c, false);
 		run_until_idle(c, true);
+		TL_RUN
 		pool_arrive<K>(execs, u, ring, c.k, c.cnt, c.lane);
 		TL_DONE(u)
 	}
@@ -252,9 +259,9 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 	FlatCtx<K> c;
 	c.k = k;
 	c.lane = threadIdx.x & 63;
-	c.sel = uniptr(pipe->sel);
-	c.lds_tables = lds;
-	c.q = (uint16_t *)(lds + table_dwords + (size_t)wave_in_block * lds_per_wave);
+	c.sel = as_global(uniptr(pipe->sel));
+	c.lds_tables = as_lds((const uint32_t *)lds);
+	c.q = as_lds((uint16_t *)(lds + table_dwords + (size_t)wave_in_block * lds_per_wave));
 #pragma unroll
 	for (int p = 0; p < K; p++) {
 		c.qsize[p] = c.cnt[p] = 0;
@@ -290,6 +297,7 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		c.in_pos = u.begin;
 		c.in_end = (uint64_t)u.begin + u.count;
 		flat_run_unit<K>(c);
+		TL_RUN
 		pool_arrive<K>(execs, u, ring, c.k, c.cnt, c.lane);
 		TL_DONE(u)
 	}

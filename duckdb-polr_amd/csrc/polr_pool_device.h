@@ -258,9 +258,10 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 
 // one lane: take a ticket of a non-blocking queue if it has one (compare-and-swap on its head while head < tail) and
 // read its entry (being written by the router that reserved it)
-__device__ __forceinline__ bool polr_pool_try_claim(unsigned long long *head, unsigned long long *tail, PoolEntry *entries,
-                                                    uint32_t cap, uint32_t wave_in_ring, uint32_t lottery,
-                                                    unsigned long long &g0, unsigned long long &g1, uint32_t &tag) {
+__device__ __forceinline__ bool polr_pool_try_claim(POLR_GLOBAL unsigned long long *head, POLR_GLOBAL unsigned long long *tail,
+                                                    POLR_GLOBAL PoolEntry *entries, uint32_t cap, uint32_t wave_in_ring,
+                                                    uint32_t lottery, unsigned long long &g0, unsigned long long &g1,
+                                                    uint32_t &tag) {
 	const unsigned long long hh = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const unsigned long long ht = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	if (hh >= ht || (((uint32_t)hh ^ wave_in_ring) & (lottery - 1u)) != 0) {
@@ -271,7 +272,7 @@ __device__ __forceinline__ bool polr_pool_try_claim(unsigned long long *head, un
 	                                          __HIP_MEMORY_SCOPE_AGENT)) {
 		return false;
 	}
-	PoolEntry *e = entries + (hh & (cap - 1u));
+	POLR_GLOBAL PoolEntry *e = entries + (hh & (cap - 1u));
 	tag = polr_pool_tag(hh, cap);
 	const unsigned long long t1 = wall_clock64();
 	while (true) {
@@ -288,29 +289,31 @@ __device__ __forceinline__ bool polr_pool_try_claim(unsigned long long *head, un
 // Take the next unit for this wave (all lanes get the same answer).  lo_ticket: the lo ticket this wave holds
 // (~0ull: none) -- kept across calls, because a wave that holds a not-yet-written lo ticket serves hi units meanwhile.
 // Returns false when the wave has to leave (EXIT entry, abort or watchdog).
-__device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run, PoolSync *sync, uint32_t ring, uint32_t lo_cap,
+// (all accesses name the global address space: a probe wave polls between LDS-heavy units, see polr_device.h)
+__device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run_generic, PoolSync *sync_generic, uint32_t ring, uint32_t lo_cap,
                                                     uint32_t hi_cap, uint32_t wave_in_ring, uint32_t lottery,
                                                     unsigned long long &lo_ticket, unsigned long long &mid_ticket,
                                                     PoolUnit &u, uint32_t lane) {
-	PoolRingCtl *ctl = &sync->ctl[ring];
+	POLR_GLOBAL PoolRun *run = as_global(run_generic);
+	POLR_GLOBAL PoolRingCtl *ctl = as_global(&sync_generic->ctl[ring]);
+	POLR_GLOBAL PoolEntry *hi_q = as_global(polr_pool_hi(sync_generic, ring, lo_cap, hi_cap));
+	POLR_GLOBAL PoolEntry *mid_q = as_global(polr_pool_mid(sync_generic, ring, lo_cap));
+	POLR_GLOBAL PoolEntry *lo_q = as_global(polr_pool_lo(sync_generic, ring, lo_cap));
 	uint32_t spins = 0;
 	while (true) {
 		unsigned long long g0 = 0, g1 = 0;
 		uint32_t tag = 0, got = 0;
 		if (lane == 0) {
 			// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
-			got = polr_pool_try_claim(&ctl->hi_head, &ctl->hi_tail, polr_pool_hi(sync, ring, lo_cap, hi_cap), hi_cap,
-			                          wave_in_ring, lottery, g0, g1, tag)
-			          ? 1u
-			          : 0u;
+			got = polr_pool_try_claim(&ctl->hi_head, &ctl->hi_tail, hi_q, hi_cap, wave_in_ring, lottery, g0, g1, tag) ? 1u : 0u;
 			if (!got) {
 				// (2) the mid queue: hold one ticket, look whether its entry has been written.  (Blocking tickets, like lo:
 				// compare-and-swap claims of the hundreds of units of an exploit round were measured slower than FIFO
 				// blocking behind them.  A mid unit waits at most for the unit its ticket holder is busy with.)
 				if (mid_ticket == ~0ull) {
-					mid_ticket = atomicAdd(&ctl->mid_head, 1ull);
+					mid_ticket = __hip_atomic_fetch_add(&ctl->mid_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				PoolEntry *e = polr_pool_mid(sync, ring, lo_cap) + (mid_ticket & (lo_cap - 1u));
+				POLR_GLOBAL PoolEntry *e = mid_q + (mid_ticket & (lo_cap - 1u));
 				tag = polr_pool_tag(mid_ticket, lo_cap);
 				g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -322,9 +325,9 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run, PoolSync *sync
 			if (!got) {
 				// (3) the lo queue: hold one ticket, look whether its entry has been written
 				if (lo_ticket == ~0ull) {
-					lo_ticket = atomicAdd(&ctl->lo_head, 1ull);
+					lo_ticket = __hip_atomic_fetch_add(&ctl->lo_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				PoolEntry *e = polr_pool_lo(sync, ring, lo_cap) + (lo_ticket & (lo_cap - 1u));
+				POLR_GLOBAL PoolEntry *e = lo_q + (lo_ticket & (lo_cap - 1u));
 				tag = polr_pool_tag(lo_ticket, lo_cap);
 				g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

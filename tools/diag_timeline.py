@@ -14,6 +14,7 @@ rec = np.concatenate([tl[w, :used[w]] for w in waves]).astype(np.int64)
 wait0, got, done, meta = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
 count = meta & 0xFFFFFFFF
 path = (meta >> 32) & 0xFF
+probe_q = (meta >> 56) & 0xFF  # quarter microseconds between "got the unit" and "pipeline empty" (saturates at 63.75)
 t0 = wait0.min()
 t1 = done.max()
 span = (t1 - t0) / 100.0
@@ -29,8 +30,10 @@ for lo, hi in ((0, 512), (512, 4096), (4096, 16384), (16384, 1 << 30)):
     m = (count > lo) & (count <= hi)
     if m.any():
         d = (done - got)[m] / 100.0
-        print("units of (%d, %d] tuples: %d, tuples %d, busy %.1f%% of all busy, mean %.2f us, ns/tuple %.3f" %
-              (lo, hi, m.sum(), count[m].sum(), 100 * d.sum() / busy, d.mean(), 1e3 * d.sum() / count[m].sum()))
+        print("units of (%d, %d] tuples: %d, tuples %d, busy %.1f%% of all busy, mean %.2f us (probing %.2f us, rest = "
+              "counters + arrival), ns/tuple %.3f" %
+              (lo, hi, m.sum(), count[m].sum(), 100 * d.sum() / busy, d.mean(), probe_q[m].mean() / 4.0,
+               1e3 * d.sum() / count[m].sum()))
 for p in np.unique(path):
     m = (path == p) & (count >= 4096)
     if m.any():
