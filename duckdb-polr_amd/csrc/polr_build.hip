@@ -31,8 +31,24 @@ __global__ void polr_deserialize_col_kernel(const uint8_t *__restrict__ rows, ui
 }
 
 // ---- key normalisation ---------------------------------------------------------------------------
-// same convention as fetch_key() in polr_probe.hip: zero-extended bit pattern; two 32-bit keys packed
-__device__ __forceinline__ bool build_key(const DevCol *keys, uint32_t n_keys, uint64_t r, uint64_t &key) {
+__device__ __forceinline__ uint64_t build_cell(const DevCol &col, uint64_t r, bool sx) {
+	const uint8_t *p = col.data + r * col.width;
+	switch (col.width) {
+	case 1:
+		return sx ? (uint64_t)(int64_t)(int8_t)*p : (uint64_t)*p;
+	case 2:
+		return sx ? (uint64_t)(int64_t) * (const int16_t *)p : (uint64_t) * (const uint16_t *)p;
+	case 4:
+		return sx ? (uint64_t)(int64_t) * (const int32_t *)p : (uint64_t) * (const uint32_t *)p;
+	default:
+		return *(const uint64_t *)p;
+	}
+}
+
+// same convention as fetch_key() in polr_probe_device.h: plain form = zero-extended bit pattern, two 32-bit keys
+// packed; packed form = sum of (value - min) << shift (KeyPack, polr_device.h)
+__device__ __forceinline__ bool build_key(const DevCol *keys, uint32_t n_keys, uint64_t r, const KeyPack &pack,
+                                          uint64_t &key) {
 	key = 0;
 	bool valid = true;
 	for (uint32_t c = 0; c < n_keys; c++) {
@@ -40,25 +56,42 @@ __device__ __forceinline__ bool build_key(const DevCol *keys, uint32_t n_keys, u
 		if (col.valid && !col.valid[r]) {
 			valid = false;
 		}
-		uint64_t v = 0;
-		const uint8_t *p = col.data + r * col.width;
-		switch (col.width) {
-		case 1:
-			v = *p;
-			break;
-		case 2:
-			v = *(const uint16_t *)p;
-			break;
-		case 4:
-			v = *(const uint32_t *)p;
-			break;
-		default:
-			v = *(const uint64_t *)p;
-			break;
+		if (pack.packed) {
+			key |= (build_cell(col, r, pack.sx[c] != 0) - (uint64_t)pack.min[c]) << pack.shift[c];
+		} else {
+			const uint64_t v = build_cell(col, r, false);
+			key = c == 0 ? v : (key | (v << 32));
 		}
-		key = c == 0 ? v : (key | (v << 32));
 	}
 	return valid;
+}
+
+// per key column: min and max of the (sign- or zero-extended) values of the rows whose keys are all valid, compared
+// as int64; out[2c] = min, out[2c+1] = max (initialised to INT64_MAX / INT64_MIN by the launcher)
+__global__ void polr_key_minmax_kernel(const DevCol *__restrict__ keys, uint32_t n_keys, uint64_t n_rows,
+                                       long long *out) {
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool valid = r < n_rows;
+	for (uint32_t c = 0; c < n_keys && valid; c++) {
+		if (keys[c].valid && !keys[c].valid[r]) {
+			valid = false;
+		}
+	}
+	for (uint32_t c = 0; c < n_keys; c++) {
+		long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
+		if (valid) {
+			lo = hi = (long long)build_cell(keys[c], r, (keys[c].flags & 1u) != 0);
+		}
+		for (int d = 32; d > 0; d >>= 1) {
+			const long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+			lo = l2 < lo ? l2 : lo;
+			hi = h2 > hi ? h2 : hi;
+		}
+		if ((threadIdx.x & 63) == 0 && lo <= hi) {
+			atomicMin(&out[2 * c], lo);
+			atomicMax(&out[2 * c + 1], hi);
+		}
+	}
 }
 
 __global__ void polr_s16_init_kernel(uint4 *slots, uint64_t capacity) {
@@ -69,7 +102,7 @@ __global__ void polr_s16_init_kernel(uint4 *slots, uint64_t capacity) {
 }
 
 // pass 1: claim a slot per distinct key (64-bit CAS on the key half) and count the run length
-__global__ void polr_s16_insert_kernel(const DevCol *__restrict__ keys, uint32_t n_keys, uint64_t n_rows,
+__global__ void polr_s16_insert_kernel(const DevCol *__restrict__ keys, uint32_t n_keys, uint64_t n_rows, KeyPack pack,
                                        uint4 *slots, uint64_t mask, uint32_t *__restrict__ slot_of_row,
                                        uint32_t *sentinel_count, unsigned long long *n_valid) {
 	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +110,7 @@ __global__ void polr_s16_insert_kernel(const DevCol *__restrict__ keys, uint32_t
 		return;
 	}
 	uint64_t key;
-	if (!build_key(keys, n_keys, r, key)) {
+	if (!build_key(keys, n_keys, r, pack, key)) {
 		slot_of_row[r] = 0xFFFFFFFFu; // NULL key: dropped (join_hashtable.cpp:170-192)
 		return;
 	}
@@ -399,8 +432,15 @@ extern "C++" void polr_launch_deserialize_col(hipStream_t st, const uint8_t *row
 	                   offset, width, dst, dst_valid);
 }
 
-extern "C++" void polr_launch_s16_build(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows,
-                                        uint4 *slots, uint64_t capacity, uint32_t *slot_of_row, uint32_t *cursor,
+extern "C++" void polr_launch_key_minmax(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows,
+                                         long long *out /* [2 * n_keys], initialised by the caller */) {
+	if (n_rows) {
+		hipLaunchKernelGGL(polr_key_minmax_kernel, grid1d(n_rows, 256), dim3(256), 0, st, keys_dev, n_keys, n_rows, out);
+	}
+}
+
+extern "C++" void polr_launch_s16_build(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, const KeyPack &pack,
+                                        uint64_t n_rows, uint4 *slots, uint64_t capacity, uint32_t *slot_of_row, uint32_t *cursor,
                                         uint32_t *rowids, uint32_t *block_sums, uint32_t *scalars
                                         /* [0]=sentinel_count [1]=max_run [2]=total [3]=sentinel_cursor */,
                                         unsigned long long *n_valid) {
@@ -408,7 +448,7 @@ extern "C++" void polr_launch_s16_build(hipStream_t st, const DevCol *keys_dev, 
 	hipLaunchKernelGGL(polr_s16_init_kernel, grid1d(capacity, 256), dim3(256), 0, st, slots, capacity);
 	if (n_rows) {
 		hipLaunchKernelGGL(polr_s16_insert_kernel, grid1d(n_rows, 256), dim3(256), 0, st, keys_dev, n_keys, n_rows,
-		                   slots, mask, slot_of_row, &scalars[0], n_valid);
+		                   pack, slots, mask, slot_of_row, &scalars[0], n_valid);
 	}
 	const uint32_t n_blocks = (uint32_t)((capacity + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS));
 	hipLaunchKernelGGL(polr_scan_reduce_kernel, dim3(n_blocks), dim3(SCAN_BLOCK), 0, st, slots, capacity, block_sums,

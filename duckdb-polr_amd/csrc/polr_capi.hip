@@ -194,15 +194,23 @@ static int check_key_shape(polr_ctx *ctx, const std::vector<OwnedCol> &keys) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "%zu equality keys per join not supported (1..%d)", keys.size(),
 		          POLR_MAX_KEYS);
 	}
-	if (keys.size() == 2 && (keys[0].width > 4 || keys[1].width > 4)) {
-		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "composite keys must be two columns of <= 32 bits");
-	}
 	for (auto &k : keys) {
 		if (k.width > 8) {
 			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "VARCHAR join keys are outside this path");
 		}
+		if (k.width != 1 && k.width != 2 && k.width != 4 && k.width != 8) {
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join key of %u bytes", k.width);
+		}
 	}
 	return POLR_OK;
+}
+
+// composite keys outside the plain {key0 | key1 << 32} form are packed exactly (KeyPack)
+static bool needs_key_pack(const polr_ht *ht) {
+	if (ht->n_keys >= 3) {
+		return true;
+	}
+	return ht->n_keys == 2 && (ht->keys[0].width > 4 || ht->keys[1].width > 4);
 }
 
 extern "C" {
@@ -341,6 +349,52 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
 	const uint64_t n = ht->n_rows_in;
+	ht->pack = KeyPack();
+	if (needs_key_pack(ht)) {
+		// per-column [min, max] of the build keys (rows with a NULL key never match and do not count)
+		long long h_mm[2 * POLR_NKEYS];
+		for (uint32_t c = 0; c < POLR_NKEYS; c++) {
+			h_mm[2 * c] = 0x7FFFFFFFFFFFFFFFll;
+			h_mm[2 * c + 1] = -0x7FFFFFFFFFFFFFFFll - 1;
+		}
+		long long *mm = nullptr;
+		int rc0 = dev_alloc(ctx, (void **)&mm, sizeof(h_mm), nullptr);
+		if (rc0) {
+			return rc0;
+		}
+		hipError_t e = hipMemcpyAsync(mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, st);
+		if (e == hipSuccess) {
+			polr_launch_key_minmax(st, ht->keys_dev, ht->n_keys, n, mm);
+			e = hipMemcpyAsync(h_mm, mm, sizeof(h_mm), hipMemcpyDeviceToHost, st);
+		}
+		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+		hipFree(mm);
+		if (e != hipSuccess) {
+			POLR_FAIL(ctx, POLR_E_HIP, "key range scan failed: %s", hipGetErrorString(e));
+		}
+		uint32_t shift = 0;
+		ht->pack.packed = 1;
+		for (uint32_t c = 0; c < ht->n_keys; c++) {
+			const bool empty = h_mm[2 * c] > h_mm[2 * c + 1]; // no row with valid keys at all
+			const int64_t lo = empty ? 0 : h_mm[2 * c], hi = empty ? 0 : h_mm[2 * c + 1];
+			const uint64_t range = (uint64_t)hi - (uint64_t)lo;
+			uint32_t bits = 0;
+			while (bits < 64 && (range >> bits) != 0) {
+				bits++;
+			}
+			if (shift + bits > 64) {
+				ht->pack = KeyPack();
+				POLR_FAIL(ctx, POLR_E_UNSUPPORTED,
+				          "composite key of %u columns needs more than 64 bits (column %u: range %llu after %u bits)",
+				          ht->n_keys, c, (unsigned long long)range, shift);
+			}
+			ht->pack.shift[c] = shift;
+			ht->pack.sx[c] = (ht->keys[c].flags & 1u) ? 1u : 0u;
+			ht->pack.min[c] = lo;
+			ht->pack.range[c] = range;
+			shift += bits;
+		}
+	}
 	// load factor <= 0.5 like PointerTableCapacity (join_hashtable.hpp:265-267), floor 1024 slots
 	const uint64_t capacity = next_pow2_u64(std::max<uint64_t>(2 * n, 1024));
 	if (capacity > (1ull << 31)) {
@@ -378,7 +432,7 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
 		e = e == hipSuccess ? hipMemsetAsync(scalars, 0, 16, st) : e;
 		e = e == hipSuccess ? hipMemsetAsync(n_valid, 0, 8, st) : e;
 		if (e == hipSuccess) {
-			polr_launch_s16_build(st, ht->keys_dev, ht->n_keys, n, slots, capacity, slot_of_row, cursor, rowids,
+			polr_launch_s16_build(st, ht->keys_dev, ht->n_keys, ht->pack, n, slots, capacity, slot_of_row, cursor, rowids,
 			                      block_sums, scalars, n_valid);
 			e = hipMemcpyAsync(h_scalars, scalars, 16, hipMemcpyDeviceToHost, st);
 			e = e == hipSuccess ? hipMemcpyAsync(&h_valid, n_valid, 8, hipMemcpyDeviceToHost, st) : e;
@@ -743,6 +797,8 @@ struct HtMeta {
 	uint64_t n_rows_in, n_rows, capacity, max_run, range;
 	int64_t min_value, max_value;
 	uint32_t key_width[POLR_MAX_KEYS];
+	uint32_t key_flags[POLR_MAX_KEYS];
+	KeyPack pack;
 	uint32_t payload_width[62];
 	uint32_t payload_flags[62];
 	uint8_t payload_has_valid[62];
@@ -819,7 +875,9 @@ int polr_ht_export(const polr_ht *ht, void *meta, uint64_t *meta_bytes, void **d
 	m.max_value = ht->max_value;
 	for (uint32_t i = 0; i < ht->n_keys; i++) {
 		m.key_width[i] = ht->keys[i].width;
+		m.key_flags[i] = ht->keys[i].flags;
 	}
+	m.pack = ht->pack;
 	const std::vector<OwnedCol> &cols = ht->kind == KIND_PERFECT ? ht->pcols : ht->payload;
 	for (uint32_t i = 0; i < ht->n_payload; i++) {
 		m.payload_width[i] = cols[i].width;
@@ -866,9 +924,10 @@ int polr_ht_alloc_like(polr_ctx *ctx, const void *meta, uint64_t meta_bytes, pol
 	ht->keys.resize(m.n_keys);
 	for (uint32_t i = 0; i < m.n_keys; i++) {
 		ht->keys[i].width = m.key_width[i];
-		ht->keys[i].flags = m.key_signed;
+		ht->keys[i].flags = m.n_keys == 1 ? m.key_signed : m.key_flags[i];
 		ht->keys[i].owned = false;
 	}
+	ht->pack = m.pack;
 	int rc = POLR_OK;
 	const uint64_t rows = m.kind == KIND_PERFECT ? m.capacity : m.n_rows_in;
 	if (m.kind == KIND_PERFECT) {
@@ -968,6 +1027,7 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 					d.key_valid[c] = col.valid;
 				}
 			}
+			d.pack = ht->pack;
 			d.table = ht->table;
 			d.rowids = ht->rowids;
 			d.mask = dj.mask;

@@ -52,6 +52,19 @@ enum { KIND_NONE = 0, KIND_PERFECT = 1, KIND_S8 = 2, KIND_S16 = 3 };
 #define S8_EMPTY_ROW 0xFFFFFFFFu
 #define S16_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
+#define POLR_NKEYS 4 // = POLR_MAX_KEYS of the ABI
+
+// Composite keys that do not fit the plain {key0 | key1 << 32} form: column c contributes (value - min[c]) << shift[c],
+// value sign- or zero-extended by the BUILD column's type; a probe value outside [min, min + range] cannot match.
+struct KeyPack {
+	uint32_t packed; // 0: plain form
+	uint32_t shift[POLR_NKEYS];
+	uint32_t sx[POLR_NKEYS]; // sign-extend column c
+	uint32_t pad[3];
+	int64_t min[POLR_NKEYS];
+	uint64_t range[POLR_NKEYS];
+};
+
 struct DevCol {
 	const uint8_t *data;
 	const uint8_t *valid; // nullptr = all valid
@@ -62,10 +75,10 @@ struct DevCol {
 struct DevJoin {
 	uint32_t kind;
 	uint32_t n_keys;
-	uint32_t key_width[2];
+	uint32_t key_width[POLR_NKEYS];
 	uint32_t key_signed;
-	int32_t key_src_join[2];
-	int32_t key_src_col[2];
+	int32_t key_src_join[POLR_NKEYS];
+	int32_t key_src_col[POLR_NKEYS];
 	uint32_t n_payload;
 	uint64_t mask;         // hash: capacity - 1
 	int64_t min_value;     // perfect
@@ -87,12 +100,12 @@ struct DevPath {
 struct StageDesc {
 	uint32_t kind;
 	uint32_t n_keys;
-	uint32_t key_width[2];
+	uint32_t key_width[POLR_NKEYS];
 	uint32_t key_signed;
-	int32_t key_slot[2];        // tuple slot whose value indexes key column c (0 = probe row)
-	int32_t out_slot;           // tuple slot that receives this join's build id, -1: not carried
-	const uint8_t *key_data[2];
-	const uint8_t *key_valid[2];
+	int32_t key_slot[POLR_NKEYS]; // tuple slot whose value indexes key column c (0 = probe row)
+	int32_t out_slot;             // tuple slot that receives this join's build id, -1: not carried
+	const uint8_t *key_data[POLR_NKEYS];
+	const uint8_t *key_valid[POLR_NKEYS];
 	const void *table;
 	const uint32_t *rowids;
 	uint64_t mask;
@@ -102,6 +115,7 @@ struct StageDesc {
 	uint32_t sentinel_count;
 	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1); 2: keys may repeat
 	uint32_t lds_off1; // flat pipelines: 1 + dword offset of this join's bit table in the workgroup's LDS table area; 0 = HBM
+	KeyPack pack;      // composite keys in packed form (read from the descriptor at use: the rare case)
 };
 #define STAGE_DESC_DWORDS (sizeof(StageDesc) / 4)
 

@@ -94,7 +94,8 @@ struct Tuple {
 
 // per-stage descriptor pulled from LDS into wave-uniform registers
 struct Stage {
-	uint32_t kind, n_keys, key_width0, key_width1, key_signed;
+	uint32_t kind, n_keys, key_width0, key_width1, key_signed, packed;
+	const StageDesc *desc; // the descriptor in LDS (packed composite keys read theirs from there)
 	int32_t key_slot0, key_slot1, out_slot;
 	const uint8_t *key_data0, *key_valid0, *key_data1, *key_valid1;
 	const void *table;
@@ -109,6 +110,8 @@ __device__ __forceinline__ Stage load_stage(const StageDesc *d) {
 	Stage s;
 	s.kind = uni(d->kind);
 	s.n_keys = uni(d->n_keys);
+	s.packed = uni(d->pack.packed);
+	s.desc = d;
 	s.key_width0 = uni(d->key_width[0]);
 	s.key_width1 = uni(d->key_width[1]);
 	s.key_signed = uni(d->key_signed);
@@ -146,6 +149,31 @@ __device__ __forceinline__ bool fetch_key(const Stage &s, const Tuple<W> &t, boo
 	key = 0;
 	if (!active) {
 		return false;
+	}
+	if (s.packed) {
+		// composite key in packed form (KeyPack): per column (value - min) << shift; a value outside the build side's
+		// [min, min + range] cannot match.  Everything comes from the LDS descriptor: the uncommon case pays a few LDS
+		// reads instead of every pipeline carrying four key columns in scalar registers.
+		const StageDesc *d = s.desc;
+		bool valid = true;
+		for (uint32_t c = 0; c < s.n_keys; c++) {
+			const uint32_t row = tuple_slot<W>(t, d->key_slot[c]);
+			const uint8_t *kv = d->key_valid[c];
+			if (kv && !kv[row]) {
+				valid = false;
+			}
+			const uint32_t w = d->key_width[c];
+			const uint64_t v = load_cell(d->key_data[c] + (uint64_t)row * w, w, d->pack.sx[c] != 0);
+			const uint64_t off = v - (uint64_t)d->pack.min[c];
+			if (off > d->pack.range[c]) {
+				valid = false;
+			}
+			key |= off << d->pack.shift[c];
+		}
+		if (!valid) {
+			key = 0;
+		}
+		return valid;
 	}
 	const bool sx = s.kind == KIND_PERFECT && s.key_signed != 0;
 	const uint32_t row0 = tuple_slot<W>(t, s.key_slot0);

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_PKG))  # duckdb-polr_amd/
 LIB_PATH = os.path.join(_ROOT, "libpolr_hip.so")
 
-MAX_JOINS, MAX_PATHS, MAX_KEYS = 8, 32, 2
+MAX_JOINS, MAX_PATHS, MAX_KEYS = 8, 32, 4
 COL_SIGNED, COL_DEVICE = 1, 2
 
 OK, E_NO_DEVICE, E_INVALID, E_UNSUPPORTED, E_HIP, E_DUPLICATE, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6

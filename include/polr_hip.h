@@ -29,7 +29,10 @@ extern "C" {
 
 #define POLR_MAX_JOINS 8   /* consecutive INNER hash joins multiplexed in one pipeline */
 #define POLR_MAX_PATHS 32  /* >= max_join_orders used by the reference's experiments (24) */
-#define POLR_MAX_KEYS 2    /* equality conditions per join (composite keys up to 2 x 32 bit) */
+#define POLR_MAX_KEYS 4    /* equality conditions per join.  Two columns of <= 32 bits, or one of <= 64, are compared as
+                            * they are; any other combination (3 or 4 keys, a wide column in a composite) is packed
+                            * EXACTLY into 64 bits from the build side's per-column [min, max] (sum of the columns' range
+                            * bits <= 64, else POLR_E_UNSUPPORTED): never a hash, so no verification pass */
 
 enum {
 	POLR_OK = 0,

@@ -31,6 +31,39 @@ def test_bcast_build_world_of_one(gpu_ctx):
     comm.close()
 
 
+def test_bcast_build_keeps_a_packed_composite_key(gpu_ctx):
+    """the per-column [min, max] packing of a three-key table travels in the metadata blob"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    bk = [rng.integers(-40, 40, 3000).astype(np.int32), rng.integers(0, 9, 3000).astype(np.uint8),
+          rng.integers(100, 130, 3000).astype(np.int16)]
+    ht = capi.HashTable.from_columns(gpu_ctx, bk, [])
+    ht.finalize_hash()
+    meta, bufs = ht.export()
+    clone = capi.HashTable.alloc_like(gpu_ctx, meta)
+    _m2, bufs2 = clone.export()
+    for (src, n), (dst, n2) in zip(bufs, bufs2):
+        assert n == n2
+        if n:
+            _d2d(dst, src, n)
+    pick = rng.integers(0, 3000, 8000)
+    pk = [b[pick].copy() for b in bk]
+    pk[0][::5] += 1000  # out of range: no match
+    counts = []
+    for t in (ht, clone):
+        pipe = capi.Pipeline(gpu_ctx, pk, 8000, [(t, [(-1, 0), (-1, 1), (-1, 2)])], [[0]])
+        counts.append(int(pipe.probe_rounds([(0, 8000, 0, 0)]).sum()))
+        pipe.close()
+    assert counts[0] == counts[1] > 0
+
+
+def _d2d(dst, src, n):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(dst, src, n, 3) == 0
+
+
 def test_comm_api_rejects_null_arguments():
     L = capi.load()
     assert L.polr_comm_get_unique_id(None) == capi.E_INVALID

@@ -256,3 +256,76 @@ def test_full_size_bench_workload_properties(gpu_ctx):
     assert len(set(answers.values())) == 1, answers
     # the static plan never beats the adaptive ones on intermediates by construction of the workload
     # (join order 1 is far more selective first); not asserted as a law, only recorded
+
+
+def _composite_case(rng, n_build, n_probe, spec):
+    """spec: [(dtype, lo, hi)] per key column -> (build keys, probe keys): probe rows are build rows (hits), rows that
+    differ from a build row in ONE column (near misses), and rows with a value outside the build side's range"""
+    bk = [rng.integers(lo, hi, n_build).astype(dt) for dt, lo, hi in spec]
+    pick = rng.integers(0, n_build, n_probe)
+    pk = [b[pick].copy() for b in bk]
+    for c, (dt, lo, hi) in enumerate(spec):
+        miss = rng.random(n_probe) < 0.15
+        pk[c][miss] = rng.integers(lo, hi, int(miss.sum())).astype(dt)
+        info = np.iinfo(dt)
+        far = rng.random(n_probe) < 0.03  # outside [min, max] of the build column, both sides of it
+        pk[c][far] = np.where(rng.random(int(far.sum())) < 0.5, max(info.min, lo - 7), min(info.max, hi + 7)).astype(dt)
+    return bk, pk
+
+
+def test_three_and_four_key_joins(gpu_ctx):
+    """more than two equality conditions per join (PhysicalHashJoin takes any number, physical_hash_join.cpp:22-60): the
+    device packs the columns exactly from the build side's ranges; duplicates, negatives, near misses, out-of-range
+    probe values, NULL keys"""
+    rng = np.random.default_rng(41)
+    spec3 = [(np.int32, -300, 300), (np.uint16, 10, 90), (np.int8, -20, 20)]
+    bk, pk = _composite_case(rng, 6000, 20000, spec3)
+    bvalid = [None, (rng.random(6000) > 0.02).astype(np.uint8), None]
+    pvalid = [None, None, (rng.random(20000) > 0.02).astype(np.uint8)]
+    pay = (np.arange(6000) % 1000).astype(np.int32)
+    rows3 = run_both(gpu_ctx, pk, [(bk, [pay], [(-1, 0), (-1, 1), (-1, 2)], None, bvalid)], [[0]], probe_valid=pvalid)
+    assert rows3 > 0
+    spec4 = [(np.int64, -2**40, -2**40 + 5000), (np.uint32, 4_000_000_000, 4_000_000_050), (np.int16, -3, 3),
+             (np.uint8, 0, 4)]
+    bk4, pk4 = _composite_case(rng, 5000, 15000, spec4)
+    # a second, single-key join so that two join orders exist and the composite join also runs at position 1
+    d = np.arange(0, 64, dtype=np.uint8)
+    rows4 = run_both(gpu_ctx, pk4, [(bk4, [], [(-1, 0), (-1, 1), (-1, 2), (-1, 3)], None, None),
+                                    ([d], [d], [(-1, 3)], None, None)], [[0, 1], [1, 0]])
+    assert rows4 > 0
+
+
+def test_two_keys_with_a_64bit_column(gpu_ctx):
+    rng = np.random.default_rng(42)
+    bk, pk = _composite_case(rng, 3000, 9000, [(np.int64, 10**12, 10**12 + 400), (np.int32, -50, 50)])
+    assert run_both(gpu_ctx, pk, [(bk, [(bk[1] * 2).astype(np.int32)], [(-1, 0), (-1, 1)], None, None)], [[0]]) > 0
+
+
+def test_composite_key_from_a_build_column(gpu_ctx):
+    """a three-key join one of whose keys is a build column of the join before it (dependent join,
+    polar_config.cpp:152-229)"""
+    rng = np.random.default_rng(43)
+    n0 = 500
+    k0 = np.arange(n0, dtype=np.int32)
+    pay0 = rng.integers(0, 30, n0).astype(np.int16)  # becomes key 2 of join 1
+    b1 = [rng.integers(0, 40, 4000).astype(np.int32), rng.integers(0, 6, 4000).astype(np.uint8),
+          rng.integers(0, 30, 4000).astype(np.int16)]
+    p0 = rng.integers(0, n0 + 20, 12000).astype(np.int32)
+    p1 = rng.integers(0, 40, 12000).astype(np.int32)
+    p2 = rng.integers(0, 6, 12000).astype(np.uint8)
+    rows = run_both(gpu_ctx, [p0, p1, p2], [([k0], [pay0], [(-1, 0)], None, None),
+                                            (b1, [], [(-1, 1), (-1, 2), (0, 0)], None, None)], [[0, 1]])
+    assert rows > 0
+
+
+def test_composite_key_wider_than_64_bits_is_refused(gpu_ctx):
+    rng = np.random.default_rng(44)
+    keys = [rng.integers(-2**31, 2**31 - 1, 1000).astype(np.int32) for _ in range(3)]
+    ht = capi.HashTable.from_columns(gpu_ctx, keys, [])
+    with pytest.raises(capi.PolrError) as e:
+        ht.finalize_hash()
+    assert e.value.code == capi.E_UNSUPPORTED and "64 bits" in str(e.value)
+    ht.close()
+    with pytest.raises(capi.PolrError) as e:
+        capi.HashTable.from_columns(gpu_ctx, keys + keys[:2], [])
+    assert e.value.code == capi.E_UNSUPPORTED
