@@ -31,6 +31,7 @@ def test_bcast_build_world_of_one(gpu_ctx):
     comm.close()
 
 
+@pytest.mark.gpu
 def test_bcast_build_keeps_a_packed_composite_key(gpu_ctx):
     """the per-column [min, max] packing of a three-key table travels in the metadata blob"""
     import numpy as np
