@@ -441,31 +441,61 @@ __device__ __forceinline__ void flat_sweep(FlatCtx<K> &c) {
 	}
 }
 
-// run one unit [in_pos, in_end) to completion: a sweep whenever a deeper stage holds a full step, else the source; at
-// the end sweeps until every queue is empty (a unit leaves nothing behind: its counters are final when it arrives).
+// One unit [in_pos, in_end) in two phases, so that the caller can look for its next unit in between:
+//   flat_run_source -- a sweep whenever a deeper stage holds a full step, else the source, until the source is used up;
+//   flat_run_drain  -- sweeps until every queue is empty (a unit leaves nothing behind: its counters are final when it
+//                      arrives).
 // (Measured and dropped: sending a small unit, or the queue remainders at the end of a unit, down ALL remaining stages
 // at once -- two round trips instead of two per stage, but keys and table words are then loaded for tuples that are
 // already dead, and on a device whose memory system is the bottleneck that costs more than the chain it saves: SF100
 // run 1.58 -> 1.77 ms.)
 template <int K>
-__device__ __forceinline__ void flat_run_unit(FlatCtx<K> &c) {
+__device__ __forceinline__ void flat_run_source(FlatCtx<K> &c) {
 	while (true) {
-		bool deep_full = false, deep_any = false;
+		bool deep_full = false;
 #pragma unroll
 		for (int p = 1; p < K; p++) {
 			if (p < (int)c.k) {
 				deep_full = deep_full || c.qsize[p] >= (uint32_t)(64 * flat_sweep_f<K>());
-				deep_any = deep_any || c.qsize[p] > 0;
 			}
 		}
 		if (deep_full) {
 			flat_sweep<K>(c);
 		} else if (c.in_pos < c.in_end) {
 			flat_stage0<K>(c);
-		} else if (deep_any) {
-			flat_sweep<K>(c);
 		} else {
 			return;
 		}
+	}
+}
+
+template <int K>
+__device__ __forceinline__ void flat_run_drain(FlatCtx<K> &c) {
+	while (true) {
+		bool deep_any = false;
+#pragma unroll
+		for (int p = 1; p < K; p++) {
+			if (p < (int)c.k) {
+				deep_any = deep_any || c.qsize[p] > 0;
+			}
+		}
+		if (!deep_any) {
+			return;
+		}
+		flat_sweep<K>(c);
+	}
+}
+
+// the first source step of the unit AFTER the current one, requested while the current one drains (same join order,
+// streamable source): flat_stage0 finds the keys in pf0 / pf1 when that unit starts
+template <int K>
+__device__ __forceinline__ void flat_prefetch_unit(FlatCtx<K> &c, uint64_t begin, uint32_t count) {
+	const FlatStage &s = c.st[0];
+	const bool streamable = c.sel == nullptr && s.valid == nullptr && (begin & 3ull) == 0 && (((uint64_t)s.keys) & 15ull) == 0;
+	if (count >= (uint32_t)FLAT_STEP0 && streamable) {
+		const uint32_t base = (uint32_t)begin + 4u * c.lane;
+		c.pf0 = load_global_x4(s.keys + base);
+		c.pf1 = load_global_x4(s.keys + base + 256u);
+		c.pf_pos = begin;
 	}
 }

@@ -286,68 +286,100 @@ __device__ __forceinline__ bool polr_pool_try_claim(POLR_GLOBAL unsigned long lo
 	return true;
 }
 
-// Take the next unit for this wave (all lanes get the same answer).  lo_ticket: the lo ticket this wave holds
-// (~0ull: none) -- kept across calls, because a wave that holds a not-yet-written lo ticket serves hi units meanwhile.
-// Returns false when the wave has to leave (EXIT entry, abort or watchdog).
+// What a probe wave knows about its ring between polls: the queue bases and the tickets it holds (a wave that holds a
+// not-yet-written mid / lo ticket serves hi units meanwhile, so the tickets are kept across calls).
 // (all accesses name the global address space: a probe wave polls between LDS-heavy units, see polr_device.h)
-__device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run_generic, PoolSync *sync_generic, uint32_t ring, uint32_t lo_cap,
-                                                    uint32_t hi_cap, uint32_t wave_in_ring, uint32_t lottery,
-                                                    unsigned long long &lo_ticket, unsigned long long &mid_ticket,
-                                                    PoolUnit &u, uint32_t lane) {
-	POLR_GLOBAL PoolRun *run = as_global(run_generic);
-	POLR_GLOBAL PoolRingCtl *ctl = as_global(&sync_generic->ctl[ring]);
-	POLR_GLOBAL PoolEntry *hi_q = as_global(polr_pool_hi(sync_generic, ring, lo_cap, hi_cap));
-	POLR_GLOBAL PoolEntry *mid_q = as_global(polr_pool_mid(sync_generic, ring, lo_cap));
-	POLR_GLOBAL PoolEntry *lo_q = as_global(polr_pool_lo(sync_generic, ring, lo_cap));
-	uint32_t spins = 0;
-	while (true) {
-		unsigned long long g0 = 0, g1 = 0;
-		uint32_t tag = 0, got = 0;
-		if (lane == 0) {
-			// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
-			got = polr_pool_try_claim(&ctl->hi_head, &ctl->hi_tail, hi_q, hi_cap, wave_in_ring, lottery, g0, g1, tag) ? 1u : 0u;
-			if (!got) {
-				// (2) the mid queue: hold one ticket, look whether its entry has been written.  (Blocking tickets, like lo:
-				// compare-and-swap claims of the hundreds of units of an exploit round were measured slower than FIFO
-				// blocking behind them.  A mid unit waits at most for the unit its ticket holder is busy with.)
-				if (mid_ticket == ~0ull) {
-					mid_ticket = __hip_atomic_fetch_add(&ctl->mid_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				POLR_GLOBAL PoolEntry *e = mid_q + (mid_ticket & (lo_cap - 1u));
-				tag = polr_pool_tag(mid_ticket, lo_cap);
-				g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) {
-					got = 3;
-					mid_ticket = ~0ull;
-				}
+struct PoolPoller {
+	POLR_GLOBAL PoolRun *run;
+	POLR_GLOBAL PoolRingCtl *ctl;
+	POLR_GLOBAL PoolEntry *hi_q, *mid_q, *lo_q;
+	uint32_t lo_cap, hi_cap, wave_in_ring, lottery;
+	unsigned long long lo_ticket, mid_ticket; // ~0ull: none
+};
+
+__device__ __forceinline__ void polr_pool_poller_init(PoolPoller &pp, PoolRun *run_generic, PoolSync *sync_generic,
+                                                      uint32_t ring, uint32_t lo_cap, uint32_t hi_cap,
+                                                      uint32_t wave_in_ring, uint32_t lottery) {
+	pp.run = as_global(run_generic);
+	pp.ctl = as_global(&sync_generic->ctl[ring]);
+	pp.hi_q = as_global(polr_pool_hi(sync_generic, ring, lo_cap, hi_cap));
+	pp.mid_q = as_global(polr_pool_mid(sync_generic, ring, lo_cap));
+	pp.lo_q = as_global(polr_pool_lo(sync_generic, ring, lo_cap));
+	pp.lo_cap = lo_cap;
+	pp.hi_cap = hi_cap;
+	pp.wave_in_ring = wave_in_ring;
+	pp.lottery = lottery;
+	pp.lo_ticket = pp.mid_ticket = ~0ull;
+}
+
+// ONE look at the three queues (all lanes get the same answer): POLR_POLL_NONE, _WORK (u is the unit) or _LEAVE (an
+// EXIT entry, or an entry that never arrived: the wave has to go)
+#define POLR_POLL_NONE 0u
+#define POLR_POLL_WORK 1u
+#define POLR_POLL_LEAVE 2u
+__device__ __forceinline__ uint32_t polr_pool_poll(PoolPoller &pp, PoolUnit &u, uint32_t lane) {
+	unsigned long long g0 = 0, g1 = 0;
+	uint32_t tag = 0, got = 0;
+	if (lane == 0) {
+		// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
+		got = polr_pool_try_claim(&pp.ctl->hi_head, &pp.ctl->hi_tail, pp.hi_q, pp.hi_cap, pp.wave_in_ring, pp.lottery, g0, g1,
+		                          tag)
+		          ? 1u
+		          : 0u;
+		if (!got) {
+			// (2) the mid queue: hold one ticket, look whether its entry has been written.  (Blocking tickets, like lo:
+			// compare-and-swap claims of the hundreds of units of an exploit round were measured slower than FIFO
+			// blocking behind them.  A mid unit waits at most for the unit its ticket holder is busy with.)
+			if (pp.mid_ticket == ~0ull) {
+				pp.mid_ticket = __hip_atomic_fetch_add(&pp.ctl->mid_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			if (!got) {
-				// (3) the lo queue: hold one ticket, look whether its entry has been written
-				if (lo_ticket == ~0ull) {
-					lo_ticket = __hip_atomic_fetch_add(&ctl->lo_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				POLR_GLOBAL PoolEntry *e = lo_q + (lo_ticket & (lo_cap - 1u));
-				tag = polr_pool_tag(lo_ticket, lo_cap);
-				g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) {
-					got = 2;
-					lo_ticket = ~0ull;
-				}
+			POLR_GLOBAL PoolEntry *e = pp.mid_q + (pp.mid_ticket & (pp.lo_cap - 1u));
+			tag = polr_pool_tag(pp.mid_ticket, pp.lo_cap);
+			g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) {
+				got = 3;
+				pp.mid_ticket = ~0ull;
 			}
 		}
-		got = __builtin_amdgcn_readfirstlane(got);
-		if (got) {
-			g0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g0 >> 32)) << 32) |
-			     __builtin_amdgcn_readfirstlane((uint32_t)g0);
-			g1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g1 >> 32)) << 32) |
-			     __builtin_amdgcn_readfirstlane((uint32_t)g1);
-			tag = __builtin_amdgcn_readfirstlane(tag);
-			if (!polr_pool_decode(g0, g1, tag, u)) {
-				return false; // (a hi entry that never arrived: watchdog)
+		if (!got) {
+			// (3) the lo queue: hold one ticket, look whether its entry has been written
+			if (pp.lo_ticket == ~0ull) {
+				pp.lo_ticket = __hip_atomic_fetch_add(&pp.ctl->lo_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			return u.kind == POLR_POOL_KIND_WORK;
+			POLR_GLOBAL PoolEntry *e = pp.lo_q + (pp.lo_ticket & (pp.lo_cap - 1u));
+			tag = polr_pool_tag(pp.lo_ticket, pp.lo_cap);
+			g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) {
+				got = 2;
+				pp.lo_ticket = ~0ull;
+			}
+		}
+	}
+	got = __builtin_amdgcn_readfirstlane(got);
+	if (!got) {
+		return POLR_POLL_NONE;
+	}
+	g0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g0 >> 32)) << 32) |
+	     __builtin_amdgcn_readfirstlane((uint32_t)g0);
+	g1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g1 >> 32)) << 32) |
+	     __builtin_amdgcn_readfirstlane((uint32_t)g1);
+	tag = __builtin_amdgcn_readfirstlane(tag);
+	if (!polr_pool_decode(g0, g1, tag, u)) {
+		return POLR_POLL_LEAVE; // (a hi entry that never arrived: watchdog)
+	}
+	return u.kind == POLR_POOL_KIND_WORK ? POLR_POLL_WORK : POLR_POLL_LEAVE;
+}
+
+// Take the next unit for this wave, waiting for one.  Returns false when the wave has to leave (EXIT entry, abort or
+// watchdog).
+__device__ __forceinline__ bool polr_pool_next_unit(PoolPoller &pp, PoolUnit &u, uint32_t lane) {
+	uint32_t spins = 0;
+	while (true) {
+		const uint32_t got = polr_pool_poll(pp, u, lane);
+		if (got != POLR_POLL_NONE) {
+			return got == POLR_POLL_WORK;
 		}
 		// nothing yet: back off (longer the longer nothing comes), give up when the run was given up
 		spins++;
@@ -361,7 +393,7 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolRun *run_generic, PoolSy
 			// they raise `abort`, and the last of them always publishes the EXIT entries)
 			uint32_t ab = 0;
 			if (lane == 0) {
-				ab = __hip_atomic_load(&run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				ab = __hip_atomic_load(&pp.run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			if (__builtin_amdgcn_readfirstlane(ab)) {
 				return false;
