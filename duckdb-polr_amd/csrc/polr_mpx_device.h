@@ -364,6 +364,10 @@ __device__ __forceinline__ void polr_offs_cache_fill(OffsCache &oc, const Reside
 	if (n > cap) {
 		n = cap;
 	}
+	// (never beyond the executor's own range: the boundary after its last chunk is the last entry it reads)
+	if (!x.morsel_cursor && x.chunk_end >= from && n > x.chunk_end - from + 1) {
+		n = x.chunk_end - from + 1;
+	}
 	__builtin_amdgcn_wave_barrier();
 	// 8 independent loads per lane in flight (a plain loop waits for every load before it issues the next one)
 	for (uint64_t i0 = 0; i0 < n; i0 += 64 * 8) {

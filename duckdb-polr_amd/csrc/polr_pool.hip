@@ -20,6 +20,9 @@
 #error "compile with -DPOLR_K=<compiled stage count>"
 #endif
 
+#ifdef POLR_DIAG_TIMELINE
+static __device__ unsigned long long polr_diag_router[8];
+#endif
 #include "polr_probe_device.h"
 #include "polr_flat_device.h"
 #include "polr_pool_device.h"
@@ -77,6 +80,9 @@ __device__ __forceinline__ void pool_router_wave(const ResidentExec *execs, Pool
 	if (exec >= rh.n_exec) {
 		return;
 	}
+	// a router is one wave of mostly scalar-style, dependent code that everybody else waits for: it gets the SIMD's
+	// issue slots ahead of the probe waves it shares the SIMD with
+	__builtin_amdgcn_s_setprio(3);
 	ResidentExec x;
 	pool_load_exec(execs + exec, x);
 	uint32_t *base = lds + (size_t)wave_in_block * router_dwords;
@@ -109,6 +115,13 @@ static __device__ uint32_t polr_diag_tl_cap;
 	}                                                                                                                  \
 	tl_n++;                                                                                                            \
 	tl_wait = wall_clock64();
+extern "C" int PASTE_TL(polr_diag_router_k, POLR_K)(unsigned long long *dst, int reset) {
+	unsigned long long z[8] = {};
+	if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(polr_diag_router), sizeof(z)) != hipSuccess) {
+		return -1;
+	}
+	return reset ? (hipMemcpyToSymbol(HIP_SYMBOL(polr_diag_router), z, sizeof(z)) == hipSuccess ? 0 : -1) : 0;
+}
 extern "C" int PASTE_TL(polr_diag_timeline_set_k, POLR_K)(unsigned long long *buf, uint32_t cap) {
 	if (hipMemcpyToSymbol(HIP_SYMBOL(polr_diag_tl), &buf, sizeof(buf)) != hipSuccess) {
 		return -1;

@@ -34,6 +34,20 @@
 
 #include "polr_mpx_device.h"
 
+#ifdef POLR_DIAG_TIMELINE
+// diagnostic build: router time by phase (ticks of the 100 MHz clock, summed over all routers and steps):
+// [0] waiting for the front round, [1] absorbing its counters, [2] the real routing step, [3] publishing,
+// [4] rehearsals (route + publish), [5] steps, [6] entry .. first publish, [7] routers
+#define RT_T(v_) const unsigned long long v_ = wall_clock64();
+#define RT_ADD(i_, d_)                                                                                                 \
+	if (lane == 0) {                                                                                                   \
+		atomicAdd(&polr_diag_router[i_], (unsigned long long)(d_));                                                    \
+	}
+#else
+#define RT_T(v_)
+#define RT_ADD(i_, d_)
+#endif
+
 #define POLR_POOL_RINGS 64 // unit queues; counters and arrivals are sharded 8 ways (ring & 7)
 #define POLR_POOL_SHARDS 8
 #define POLR_POOL_HI_TUPLES 4096u // rounds up to this many tuples are latency-critical (exploration slices)
@@ -383,10 +397,12 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolPoller &pp, PoolUnit &u,
 		}
 		// nothing yet: back off (longer the longer nothing comes), give up when the run was given up
 		spins++;
-		if (spins < 16) {
+		if (spins < 8) {
 			__builtin_amdgcn_s_sleep(2);
-		} else {
+		} else if (spins < 32) {
 			__builtin_amdgcn_s_sleep(16);
+		} else {
+			__builtin_amdgcn_s_sleep(64);
 		}
 		if ((spins & 15u) == 0) {
 			// (no clock of its own: an idle wave may wait as long as the run takes; the routers' waits are bounded,
@@ -408,6 +424,7 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolPoller &pp, PoolUnit &u,
 __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun *run, const PoolRun &rh, uint32_t exec,
                                                  uint32_t k, uint32_t gran, uint32_t lane, uint32_t *lds,
                                                  uint64_t *cache_lds, uint32_t cache_cap, uint32_t *scratch_lds) {
+	RT_T(rt_entry)
 	DevMpx *mg = x.mpx;
 	PoolSync *sync = rh.sync;
 	const bool reset = (x.flags & POLR_RUN_RESET) != 0;
@@ -474,6 +491,11 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
 	}
 	__builtin_amdgcn_wave_barrier();
+	if (x.chunk_offsets && !x.morsel_cursor && x.chunk_begin < x.chunk_end) {
+		// the boundaries of the first chunks, in one cooperative load (the first routing step would otherwise fetch them
+		// one dependent global load after the other on its single lane)
+		polr_offs_cache_fill(oc, x, x.chunk_begin, cache_cap, lane);
+	}
 	unsigned long long target[POLR_SLOTS];
 	if (((volatile DevMpx *)m)->res_valid) {
 #pragma unroll
@@ -556,6 +578,7 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	while (true) {
 		__builtin_amdgcn_wave_barrier();
 		const uint32_t front_slot = (n_pub - n_fly) & (POLR_SLOTS - 1u);
+		RT_T(rt0)
 		// (1) the oldest round in flight has to be complete before its counters can be absorbed
 		if (n_fly) {
 			unsigned long long want = 0;
@@ -579,6 +602,8 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 				break;
 			}
 		}
+		RT_T(rt1)
+		RT_ADD(0, rt1 - rt0)
 		// (2) the real step
 		if (!(reset && n_steps == 0)) { // (a reset run starts on the bank it dropped at entry)
 			const uint64_t got = polr_pool_absorb(m, mg, x.counts + (n_fly ? front_slot : 0u) * bank_stride, k, lane, false);
@@ -598,9 +623,14 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		}
 		n_steps++;
 		__builtin_amdgcn_wave_barrier();
+		RT_T(rt2)
+		RT_ADD(1, rt2 - rt1)
+		RT_ADD(5, 1)
 		{
 			PoolRoundOut r;
 			const bool done = route_here(r);
+			RT_T(rt3)
+			RT_ADD(2, rt3 - rt2)
 			if (n_fly > 1) {
 				// this round is already out: the real decision must be the rehearsed one, bit for bit
 				const PoolRoundOut &sp = ahead[0];
@@ -619,10 +649,17 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 					break;
 				}
 				publish(r);
+				RT_T(rt4)
+				RT_ADD(3, rt4 - rt3)
+				if (n_steps == 1) {
+					RT_ADD(6, rt4 - rt_entry)
+					RT_ADD(7, 1)
+				}
 				shadow_valid = false;
 				shadow_ended = false;
 			}
 		}
+		RT_T(rt5)
 		// (3) rehearse ahead: while the decision after the last published round cannot depend on intermediates that
 		// are still outstanding, decide it on the shadow and publish it in the next slot
 		while (n_fly < POLR_SLOTS && !shadow_ended) {
@@ -660,6 +697,8 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			}
 			publish(r2);
 		}
+		RT_T(rt6)
+		RT_ADD(4, rt6 - rt5)
 		// while the pool probes: keep the boundaries of the chunks ahead in LDS
 		{
 			const uint64_t ci = ((volatile DevMpx *)m)->chunk_idx;
