@@ -506,7 +506,8 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": None,
-                    "traffic_note": "not measured inside bench.py (PMC passes are separate rocprofv3 runs: profiles/)",
+                    "traffic_note": "not measured inside bench.py (PMC passes are separate rocprofv3 runs: profiles/) and "
+                                    "no committed PMC pass matches this command",
                     "kernel": "polr_pool_flat_kernel" if info.get("flat") else "polr_pool_kernel",
                     "algorithmic_bytes_per_step": round(alg),
                     "algorithmic_bytes_per_tuple": round(alg / max(n_tuples, 1), 3),
@@ -516,6 +517,19 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                     "working_set_bytes": int(working_set),
                     "note": "one launch = the whole pass: every executor's routing loop and all probe rounds (the kernel "
                             "time includes the device-side waits between dependent routing rounds)"}
+            sig = {"workload": name, "scale": float(scale), "routing": routing, "join_enumerator": enumerator,
+                   "max_join_orders": int(args.max_join_orders), "executors_per_gpu": int(E), "n_gpus": int(world)}
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_ssb_sf100_pmc_summary.json")))
+            except (OSError, ValueError):
+                pmc = None
+            if pmc and pmc.get("workload_signature") == sig and not args.morsels and not device_scan:
+                # REPLAYED, not measured in this run: HBM bytes per launch of the same command's separate rocprofv3
+                # --pmc passes (FETCH_SIZE, WRITE_SIZE), FETCH_SIZE corrected as calibrated for this kernel's access
+                # patterns on gfx950 (profiles/r02_fetch_size_calibration.json)
+                roof["traffic"] = int(pmc["traffic_bytes_per_launch_corrected"])
+                roof["traffic_source"] = "replayed from profiles/r02_ssb_sf100_pmc_summary.json"
+                roof["traffic_note"] = pmc["traffic_note"]
         cpu = None
         if with_cpu:
             try:
