@@ -437,7 +437,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             raise SystemExit("polr_diag_timeline_set failed")
         ph = getattr(ctx.L, "polr_diag_router_k%d" % kk)
         ph.argtypes = [C.c_void_p, C.c_int]
-        pbuf = (C.c_uint64 * 8)()
+        pbuf = (C.c_uint64 * 16)()
         ph(pbuf, 1)
         step()
         torch.cuda.synchronize()
@@ -446,8 +446,9 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         if pbuf[5]:
             n_s, n_r = float(pbuf[5]), float(max(pbuf[7], 1))
             print("routers: %d steps; mean us per step: wait %.2f absorb %.2f route %.2f publish %.2f rehearse %.2f; "
-                  "entry -> first publish %.2f us" % (pbuf[5], pbuf[0] / n_s / 100, pbuf[1] / n_s / 100, pbuf[2] / n_s / 100,
-                                                      pbuf[3] / n_s / 100, pbuf[4] / n_s / 100, pbuf[6] / n_r / 100),
+                  "entry -> state in LDS %.2f -> initialised %.2f -> first step %.2f -> first publish %.2f us" % (
+                      pbuf[5], pbuf[0] / n_s / 100, pbuf[1] / n_s / 100, pbuf[2] / n_s / 100, pbuf[3] / n_s / 100,
+                      pbuf[4] / n_s / 100, pbuf[8] / n_r / 100, pbuf[9] / n_r / 100, pbuf[10] / n_r / 100, pbuf[6] / n_r / 100),
                   file=sys.stderr)
         arr = tl.cpu().numpy().reshape(n_waves, cap_tl, 4)
         used = (arr[:, :, 2] != 0).sum(axis=1)

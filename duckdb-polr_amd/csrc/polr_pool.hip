@@ -21,7 +21,7 @@
 #endif
 
 #ifdef POLR_DIAG_TIMELINE
-static __device__ unsigned long long polr_diag_router[8];
+static __device__ unsigned long long polr_diag_router[16];
 #endif
 #include "polr_probe_device.h"
 #include "polr_flat_device.h"
@@ -116,7 +116,7 @@ static __device__ uint32_t polr_diag_tl_cap;
 	tl_n++;                                                                                                            \
 	tl_wait = wall_clock64();
 extern "C" int PASTE_TL(polr_diag_router_k, POLR_K)(unsigned long long *dst, int reset) {
-	unsigned long long z[8] = {};
+	unsigned long long z[16] = {};
 	if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(polr_diag_router), sizeof(z)) != hipSuccess) {
 		return -1;
 	}

@@ -37,7 +37,8 @@
 #ifdef POLR_DIAG_TIMELINE
 // diagnostic build: router time by phase (ticks of the 100 MHz clock, summed over all routers and steps):
 // [0] waiting for the front round, [1] absorbing its counters, [2] the real routing step, [3] publishing,
-// [4] rehearsals (route + publish), [5] steps, [6] entry .. first publish, [7] routers
+// [4] rehearsals (route + publish), [5] steps, [6] entry .. first publish, [7] routers,
+// [8] entry .. state in LDS, [9] .. state initialised, [10] .. arrival targets known (= first step begins)
 #define RT_T(v_) const unsigned long long v_ = wall_clock64();
 #define RT_ADD(i_, d_)                                                                                                 \
 	if (lane == 0) {                                                                                                   \
@@ -456,6 +457,8 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	DevMpx *m = (DevMpx *)lds;
 	volatile uint32_t *const host_words = mg->progress;
 	__builtin_amdgcn_wave_barrier();
+	RT_T(rt_e1)
+	RT_ADD(8, rt_e1 - rt_entry)
 	if (lane == 0) {
 		m->progress = nullptr; // nobody on the host follows the steps of a one-launch run
 	}
@@ -491,6 +494,8 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		m->done = x.chunk_begin >= x.chunk_end ? 1 : 0;
 	}
 	__builtin_amdgcn_wave_barrier();
+	RT_T(rt_e2)
+	RT_ADD(9, rt_e2 - rt_entry)
 	if (x.chunk_offsets && !x.morsel_cursor && x.chunk_begin < x.chunk_end) {
 		// the boundaries of the first chunks, in one cooperative load (the first routing step would otherwise fetch them
 		// one dependent global load after the other on its single lane)
@@ -515,6 +520,8 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	// rehearsed ahead on a copy of the state (the shadow) and published already -- every real step that follows must
 	// decide exactly them, in order.  Round i of the run sits in slot i % POLR_SLOTS, so the front's slot is
 	// (n_pub - n_fly) % POLR_SLOTS.
+	RT_T(rt_e3)
+	RT_ADD(10, rt_e3 - rt_entry)
 	uint32_t n_steps = 0;
 	uint32_t n_pub = 0; // rounds published so far
 	uint32_t n_fly = 0; // published, counters not absorbed yet
