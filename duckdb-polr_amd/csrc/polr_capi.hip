@@ -995,6 +995,13 @@ static void fill_dev_join(DevJoin *dj, const polr_join_desc *jd, const polr_ht *
 	dj->sentinel_start = ht->sentinel_start;
 	dj->sentinel_count = ht->sentinel_count;
 	dj->payload = ht->payload_dev;
+	dj->n_preds = jd->n_preds;
+	for (uint32_t c = 0; c < jd->n_preds && c < POLR_NPREDS; c++) {
+		dj->pred_op[c] = jd->pred_op[c];
+		dj->pred_src_join[c] = jd->pred_src_join[c];
+		dj->pred_src_col[c] = jd->pred_src_col[c];
+		dj->pred_build_col[c] = jd->pred_build_col[c];
+	}
 }
 
 // resolve every (join order, position) of a pipeline variant into a StageDesc (see polr_device.h)
@@ -1028,6 +1035,28 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 				}
 			}
 			d.pack = ht->pack;
+			d.n_preds = dj.n_preds;
+			for (uint32_t c = 0; c < dj.n_preds; c++) {
+				const int32_t sj = dj.pred_src_join[c];
+				const int32_t sc = dj.pred_src_col[c];
+				const OwnedCol &bcol = ht->kind == KIND_PERFECT ? ht->pcols[dj.pred_build_col[c]] : ht->payload[dj.pred_build_col[c]];
+				d.pred_op[c] = dj.pred_op[c];
+				d.pred_width[c] = bcol.width;
+				d.pred_sx[c] = (bcol.flags & 1u) ? 1u : 0u;
+				d.pred_bdata[c] = bcol.data;
+				d.pred_bvalid[c] = bcol.valid;
+				if (sj < 0) {
+					d.pred_slot[c] = 0;
+					d.pred_data[c] = p->probe_cols[sc].data;
+					d.pred_valid[c] = p->probe_cols[sc].valid;
+				} else {
+					const polr_ht *src = p->hts[sj];
+					const OwnedCol &col = src->kind == KIND_PERFECT ? src->pcols[sc] : src->payload[sc];
+					d.pred_slot[c] = dp.slot_of_join[sj];
+					d.pred_data[c] = col.data;
+					d.pred_valid[c] = col.valid;
+				}
+			}
 			d.table = ht->table;
 			d.rowids = ht->rowids;
 			d.mask = dj.mask;
@@ -1055,7 +1084,7 @@ static void plan_flat(polr_pipeline *p, std::vector<StageDesc> &sd_count) {
 	for (uint32_t j = 0; j < c.k; j++) {
 		const polr_ht *ht = p->hts[j];
 		const DevJoin &dj = c.joins[j];
-		if (dj.n_keys != 1 || dj.key_src_join[0] >= 0 || dj.key_width[0] != 4) {
+		if (dj.n_keys != 1 || dj.key_src_join[0] >= 0 || dj.key_width[0] != 4 || dj.n_preds != 0) {
 			return;
 		}
 		if (ht->kind == KIND_PERFECT) {
@@ -1160,6 +1189,13 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 					          sj);
 				}
 			}
+			for (uint32_t c = 0; c < joins[x].n_preds && c < POLR_MAX_PREDS; c++) {
+				const int32_t sj = joins[x].pred_src_join[c];
+				if (sj >= 0 && !((seen >> sj) & 1)) {
+					POLR_FAIL(ctx, POLR_E_INVALID, "path %u probes join %d before join %d that a condition of it reads", p, x,
+					          sj);
+				}
+			}
 			seen |= 1u << x;
 		}
 	}
@@ -1194,6 +1230,39 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 			if (width != ht->keys[c].width) {
 				POLR_FAIL(ctx, POLR_E_INVALID, "join %u key %u: probe key is %u bytes, build key %u bytes", j, c, width,
 				          ht->keys[c].width);
+			}
+		}
+		if (joins[j].n_preds > POLR_MAX_PREDS) {
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u: %u non-equality conditions (at most %d)", j, joins[j].n_preds,
+			          POLR_MAX_PREDS);
+		}
+		for (uint32_t c = 0; c < joins[j].n_preds; c++) {
+			const int32_t sj = joins[j].pred_src_join[c];
+			const int32_t sc = joins[j].pred_src_col[c];
+			const uint32_t bc = joins[j].pred_build_col[c];
+			const uint32_t op = joins[j].pred_op[c];
+			if (op < POLR_CMP_NE || op > POLR_CMP_GE) {
+				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u condition %u: comparison %u (NE, LT, GT, LE, GE)", j, c, op);
+			}
+			if (bc >= ht->n_payload) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: build column %u out of range", j, c, bc);
+			}
+			uint32_t width;
+			if (sj < 0) {
+				if (sc < 0 || (uint32_t)sc >= n_probe_cols) {
+					POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: probe column %d out of range", j, c, sc);
+				}
+				width = probe_cols[sc].width;
+			} else {
+				if ((uint32_t)sj >= k || (uint32_t)sj == j || sc < 0 || (uint32_t)sc >= joins[sj].ht->n_payload) {
+					POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: build column (%d,%d) out of range", j, c, sj, sc);
+				}
+				width = joins[sj].ht->payload[sc].width;
+			}
+			const OwnedCol &bcol = ht->kind == KIND_PERFECT ? ht->pcols[bc] : ht->payload[bc];
+			if (width != bcol.width || (width != 1 && width != 2 && width != 4 && width != 8)) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: left side is %u bytes, right side %u bytes", j, c, width,
+				          bcol.width);
 			}
 		}
 	}
@@ -1249,6 +1318,12 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 		for (uint32_t j = 0; j < k; j++) {
 			for (uint32_t cc = 0; cc < joins[j].n_keys; cc++) {
 				const int32_t sj = joins[j].key_src_join[cc];
+				if (sj >= 0 && c.slot_of_join[sj] < 0) {
+					c.slot_of_join[sj] = (int32_t)w++;
+				}
+			}
+			for (uint32_t cc = 0; cc < joins[j].n_preds; cc++) {
+				const int32_t sj = joins[j].pred_src_join[cc];
 				if (sj >= 0 && c.slot_of_join[sj] < 0) {
 					c.slot_of_join[sj] = (int32_t)w++;
 				}

@@ -53,6 +53,7 @@ enum { KIND_NONE = 0, KIND_PERFECT = 1, KIND_S8 = 2, KIND_S16 = 3 };
 #define S16_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
 #define POLR_NKEYS 4 // = POLR_MAX_KEYS of the ABI
+#define POLR_NPREDS 4 // = POLR_MAX_PREDS
 
 // Composite keys that do not fit the plain {key0 | key1 << 32} form: column c contributes (value - min[c]) << shift[c],
 // value sign- or zero-extended by the BUILD column's type; a probe value outside [min, min + range] cannot match.
@@ -88,6 +89,11 @@ struct DevJoin {
 	uint32_t sentinel_start; // S16 side entry for key == S16_EMPTY_KEY
 	uint32_t sentinel_count;
 	const DevCol *payload; // n_payload columns, indexed by build id (perfect: by key - min)
+	uint32_t n_preds;      // non-equality conditions (polr_join_desc)
+	uint32_t pred_op[POLR_NPREDS];
+	int32_t pred_src_join[POLR_NPREDS];
+	int32_t pred_src_col[POLR_NPREDS];
+	uint32_t pred_build_col[POLR_NPREDS];
 };
 
 struct DevPath {
@@ -116,6 +122,19 @@ struct StageDesc {
 	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1); 2: keys may repeat
 	uint32_t lds_off1; // flat pipelines: 1 + dword offset of this join's bit table in the workgroup's LDS table area; 0 = HBM
 	KeyPack pack;      // composite keys in packed form (read from the descriptor at use: the rare case)
+	// non-equality conditions, evaluated on every (tuple, build row) pair the equalities produce (read from the
+	// descriptor at use): left = column pred_data[c] at the row in tuple slot pred_slot[c], right = build column
+	// pred_bdata[c] at the build id
+	uint32_t n_preds;
+	uint32_t pred_op[POLR_NPREDS];
+	uint32_t pred_width[POLR_NPREDS];
+	uint32_t pred_sx[POLR_NPREDS];
+	int32_t pred_slot[POLR_NPREDS];
+	uint32_t pred_pad;
+	const uint8_t *pred_data[POLR_NPREDS];
+	const uint8_t *pred_valid[POLR_NPREDS];
+	const uint8_t *pred_bdata[POLR_NPREDS];
+	const uint8_t *pred_bvalid[POLR_NPREDS];
 };
 #define STAGE_DESC_DWORDS (sizeof(StageDesc) / 4)
 

@@ -94,7 +94,7 @@ struct Tuple {
 
 // per-stage descriptor pulled from LDS into wave-uniform registers
 struct Stage {
-	uint32_t kind, n_keys, key_width0, key_width1, key_signed, packed;
+	uint32_t kind, n_keys, key_width0, key_width1, key_signed, packed, n_preds;
 	const StageDesc *desc; // the descriptor in LDS (packed composite keys read theirs from there)
 	int32_t key_slot0, key_slot1, out_slot;
 	const uint8_t *key_data0, *key_valid0, *key_data1, *key_valid1;
@@ -111,6 +111,7 @@ __device__ __forceinline__ Stage load_stage(const StageDesc *d) {
 	s.kind = uni(d->kind);
 	s.n_keys = uni(d->n_keys);
 	s.packed = uni(d->pack.packed);
+	s.n_preds = uni(d->n_preds);
 	s.desc = d;
 	s.key_width0 = uni(d->key_width[0]);
 	s.key_width1 = uni(d->key_width[1]);
@@ -398,9 +399,53 @@ __device__ __forceinline__ void out_write(WaveCtx<W, K> &c, const Tuple<W> &t, b
 	}
 }
 
+// the join's non-equality conditions on one (tuple, build row) pair (RowOperations::Match, row_match.cpp:59-119:
+// both sides valid and `left OP right`); descriptors come from LDS -- joins that have any are rare
+template <int W>
+__device__ __forceinline__ bool preds_hold(const Stage &s, const Tuple<W> &t, uint32_t id) {
+	const StageDesc *d = s.desc;
+	bool ok = true;
+	for (uint32_t c = 0; c < s.n_preds; c++) {
+		const uint32_t row = tuple_slot<W>(t, d->pred_slot[c]);
+		const uint32_t w = d->pred_width[c];
+		const bool sx = d->pred_sx[c] != 0;
+		const uint8_t *lv = d->pred_valid[c], *rv = d->pred_bvalid[c];
+		if ((lv && !lv[row]) || (rv && !rv[id])) {
+			ok = false;
+		}
+		const uint64_t l = load_cell(d->pred_data[c] + (uint64_t)row * w, w, sx);
+		const uint64_t r = load_cell(d->pred_bdata[c] + (uint64_t)id * w, w, sx);
+		bool h;
+		if (w == 8 && !sx) {
+			switch (d->pred_op[c]) {
+			case 1: h = l != r; break;
+			case 2: h = l < r; break;
+			case 3: h = l > r; break;
+			case 4: h = l <= r; break;
+			default: h = l >= r; break;
+			}
+		} else {
+			const int64_t a = (int64_t)l, b = (int64_t)r; // (narrow unsigned values are zero-extended: same order)
+			switch (d->pred_op[c]) {
+			case 1: h = a != b; break;
+			case 2: h = a < b; break;
+			case 3: h = a > b; break;
+			case 4: h = a <= b; break;
+			default: h = a >= b; break;
+			}
+		}
+		ok = ok && h;
+	}
+	return ok;
+}
+
 // push the matches of stage POS to the next stage (or to the output when POS is the last join)
 template <int W, int K, int POS>
 __device__ __forceinline__ void emit_tuples(WaveCtx<W, K> &c, const Stage &s, Tuple<W> t, uint32_t id, bool valid) {
+	if (s.n_preds) {
+		// (inactive lanes carry arbitrary ids: evaluate on the matches only)
+		valid = valid && preds_hold<W>(s, t, id);
+	}
 #pragma unroll
 	for (int i = 1; i < W; i++) {
 		t.s[i] = (i == s.out_slot) ? id : t.s[i];
@@ -477,7 +522,7 @@ __device__ __forceinline__ void resume_expansion(WaveCtx<W, K> &c) {
 		}
 	}
 	uint32_t id = 0;
-	if (valid && s.out_slot >= 0) {
+	if (valid && (s.out_slot >= 0 || s.n_preds)) { // (the build id is needed: carried on, or read by a condition)
 		id = s.rowids[st + r];
 	}
 	emit_tuples<W, K, POS>(c, s, t, id, valid);
@@ -541,7 +586,7 @@ __device__ __forceinline__ void run_stage(WaveCtx<W, K> &c) {
 		const bool multi = __ballot(count > 1) != 0ull;
 		if (!multi) {
 			uint32_t id = 0;
-			if (count && s.out_slot >= 0) {
+			if (count && (s.out_slot >= 0 || s.n_preds)) {
 				id = s.rowids[start];
 			}
 			emit_tuples<W, K, POS>(c, s, t, id, count != 0);
@@ -696,7 +741,7 @@ __device__ __forceinline__ void run_stage_wide(WaveCtx<W, K> &c) {
 			start[i] = p[i].start;
 			cnt[i] = p[i].count;
 			multi[i] = __ballot(p[i].count > 1) != 0ull;
-			id[i] = (hit[i] && s.out_slot >= 0) ? s.rowids[p[i].start] : 0u;
+			id[i] = (hit[i] && (s.out_slot >= 0 || s.n_preds)) ? s.rowids[p[i].start] : 0u;
 		}
 	}
 	bool any_multi = false;
@@ -777,7 +822,7 @@ __device__ __forceinline__ void resume_expansion_wide(WaveCtx<W, K> &c) {
 	uint32_t id[WIDE];
 #pragma unroll
 	for (int j = 0; j < WIDE; j++) {
-		id[j] = (valid[j] && s.out_slot >= 0) ? s.rowids[pos[j]] : 0u;
+		id[j] = (valid[j] && (s.out_slot >= 0 || s.n_preds)) ? s.rowids[pos[j]] : 0u;
 	}
 #pragma unroll
 	for (int j = 0; j < WIDE; j++) {

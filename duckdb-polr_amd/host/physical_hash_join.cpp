@@ -22,6 +22,15 @@ PhysicalHashJoin::PhysicalHashJoin(polr_ctx *ctx_p, vector<LogicalType> probe_ty
 	if (conditions.size() != condition_types.size() || conditions.empty()) {
 		throw InternalException("hash join needs one type per condition");
 	}
+	for (idx_t c = 0; c < conditions.size(); c++) {
+		(conditions[c].comparison == ExpressionType::COMPARE_EQUAL ? equality_conditions : other_conditions).push_back(c);
+	}
+	if (equality_conditions.empty()) {
+		throw InternalException("a hash join needs at least one equality condition (plan_comparison_join.cpp)");
+	}
+	if (other_conditions.size() > POLR_MAX_PREDS) {
+		throw NotImplementedException("more than " + std::to_string(POLR_MAX_PREDS) + " non-equality join conditions");
+	}
 }
 
 PhysicalHashJoin::~PhysicalHashJoin() {
@@ -49,12 +58,18 @@ void PhysicalHashJoin::SinkBuildSide(const vector<Vector> &keys, const vector<Ve
 	if (join_type != JoinType::INNER) {
 		throw NotImplementedException("only INNER joins are multiplexed (polar_config.cpp:35)");
 	}
+	if (keys.size() != conditions.size()) {
+		throw InternalException("SinkBuildSide: one build column per join condition");
+	}
 	vector<polr_col> kc, pc;
-	for (auto &k : keys) {
-		kc.push_back(ColOf(k));
+	for (auto c : equality_conditions) {
+		kc.push_back(ColOf(keys[c]));
 	}
 	for (auto &p : payload) {
 		pc.push_back(ColOf(p));
+	}
+	for (auto c : other_conditions) { // (hidden: never gathered into the result)
+		pc.push_back(ColOf(keys[c]));
 	}
 	Check(ctx, polr_ht_upload_columns(ctx, kc.data(), (uint32_t)kc.size(), pc.data(), (uint32_t)pc.size(), count,
 	                                  &hash_table),
@@ -63,7 +78,7 @@ void PhysicalHashJoin::SinkBuildSide(const vector<Vector> &keys, const vector<Ve
 	uses_perfect_hash = false;
 	// physical_hash_join.cpp:463-473: try the perfect table when the planner marked the build small;
 	// a duplicate key falls back to the hash table (perfect_hash_join_executor.cpp:112-114)
-	if (perfect_join_statistics.is_build_small && conditions.size() == 1) {
+	if (perfect_join_statistics.is_build_small && conditions.size() == 1 && other_conditions.empty()) {
 		int rc = polr_ht_finalize_perfect(hash_table, perfect_join_statistics.build_min,
 		                                  perfect_join_statistics.build_max, nullptr);
 		if (rc == POLR_OK) {
@@ -122,10 +137,37 @@ unique_ptr<OperatorState> PhysicalHashJoin::MakeState(const vector<idx_t> &key_c
 	polr_join_desc jd;
 	memset(&jd, 0, sizeof(jd));
 	jd.ht = hash_table;
-	jd.n_keys = (uint32_t)conditions.size();
-	for (idx_t c = 0; c < conditions.size(); c++) {
-		jd.key_src_join[c] = -1;
-		jd.key_src_col[c] = (int32_t)c;
+	jd.n_keys = (uint32_t)equality_conditions.size();
+	for (idx_t i = 0; i < equality_conditions.size(); i++) {
+		jd.key_src_join[i] = -1;
+		jd.key_src_col[i] = (int32_t)equality_conditions[i]; // (staging column c holds the left side of condition c)
+	}
+	jd.n_preds = (uint32_t)other_conditions.size();
+	for (idx_t i = 0; i < other_conditions.size(); i++) {
+		uint32_t op;
+		switch (conditions[other_conditions[i]].comparison) {
+		case ExpressionType::COMPARE_NOTEQUAL:
+			op = POLR_CMP_NE;
+			break;
+		case ExpressionType::COMPARE_LESSTHAN:
+			op = POLR_CMP_LT;
+			break;
+		case ExpressionType::COMPARE_GREATERTHAN:
+			op = POLR_CMP_GT;
+			break;
+		case ExpressionType::COMPARE_LESSTHANOREQUALTO:
+			op = POLR_CMP_LE;
+			break;
+		case ExpressionType::COMPARE_GREATERTHANOREQUALTO:
+			op = POLR_CMP_GE;
+			break;
+		default:
+			throw NotImplementedException("join condition comparison outside =, <>, <, >, <=, >=");
+		}
+		jd.pred_op[i] = op;
+		jd.pred_src_join[i] = -1;
+		jd.pred_src_col[i] = (int32_t)other_conditions[i];
+		jd.pred_build_col[i] = (uint32_t)(build_types.size() + i);
 	}
 	int32_t path = 0;
 	Check(ctx, polr_pipeline_create(ctx, cols.data(), (uint32_t)cols.size(), STANDARD_VECTOR_SIZE, &jd, 1, &path, 1,

@@ -14,9 +14,23 @@ namespace duckdb_polr {
 
 // the probe side of a JoinCondition: a BoundReferenceExpression (or CAST of one, which the caller must
 // have materialised) on the probe chunk (joinside.hpp:17-36, polar_config.cpp:75-82)
+// the comparison of a join condition (values of src/include/duckdb/common/enums/expression_type.hpp:34-46)
+enum class ExpressionType : uint8_t {
+	COMPARE_EQUAL = 25,
+	COMPARE_NOTEQUAL = 26,
+	COMPARE_LESSTHAN = 27,
+	COMPARE_GREATERTHAN = 28,
+	COMPARE_LESSTHANOREQUALTO = 29,
+	COMPARE_GREATERTHANOREQUALTO = 30
+};
+
+// JoinCondition (src/include/duckdb/planner/joinside.hpp:22-41): left = a column of the probe chunk, right = a column
+// the build side hands over at SinkBuildSide (condition c <-> keys[c]), comparison = how they are compared.  Equalities
+// key the table; the others are evaluated on every candidate pair (JoinHashTable::predicates, join_hashtable.cpp:50-52).
 struct JoinCondition {
 	idx_t left_index = 0;
 	bool left_is_bound_ref = true;
+	ExpressionType comparison = ExpressionType::COMPARE_EQUAL;
 };
 
 // What SelSampleEnumeration reads off the plan below a join (JoinOrderNode, polar_enumeration_algo.hpp:72-83, filled by
@@ -58,6 +72,9 @@ public:
 	// (PhysicalHashJoin::Sink/Finalize physical_hash_join.cpp:217-286,337-481 -> HBM residency)
 	void SinkBuildSide(const vector<Vector> &keys, const vector<Vector> &payload, idx_t count);
 	polr_ht *hash_table = nullptr;
+	// conditions by kind (indices into `conditions`): the equalities are the table's keys, the right sides of the others
+	// ride as hidden payload columns behind the projected build columns
+	vector<idx_t> equality_conditions, other_conditions;
 	bool uses_perfect_hash = false;
 	idx_t build_count = 0;
 

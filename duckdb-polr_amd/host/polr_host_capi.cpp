@@ -367,4 +367,61 @@ int64_t polr_host_hash_join_probe(polr_ctx *ctx, const int32_t *build_keys, cons
 	}
 }
 
+// The same with a second, non-equality condition: probe_keys = build_keys AND probe_other OP build_other
+// (comparison: the reference's ExpressionType value, 26..30).  (probe row, payload cell) pairs as above.
+int64_t polr_host_hash_join_probe_cond(polr_ctx *ctx, const int32_t *build_keys, const int32_t *build_other,
+                                       const int32_t *build_payload, uint64_t n_build, int comparison,
+                                       const int32_t *probe_keys, const int32_t *probe_other, uint64_t n_probe,
+                                       uint32_t *out_probe_row, int32_t *out_payload, uint64_t out_cap) {
+	try {
+		ClientContext client;
+		ThreadContext thread;
+		ExecutionContext ec(client, thread);
+		JoinCondition eq, other;
+		eq.left_index = 0;
+		other.left_index = 1;
+		other.comparison = (ExpressionType)comparison;
+		PhysicalHashJoin join(ctx, {LogicalType::INTEGER(), LogicalType::INTEGER()},
+		                      {LogicalType::INTEGER(), LogicalType::INTEGER()}, {LogicalType::INTEGER()}, {eq, other},
+		                      JoinType::INNER, n_build);
+		const idx_t nb = n_build ? n_build : 1;
+		Vector bk(LogicalType::INTEGER(), nb), bo(LogicalType::INTEGER(), nb), bp(LogicalType::INTEGER(), nb);
+		memcpy(bk.data, build_keys, n_build * 4);
+		memcpy(bo.data, build_other, n_build * 4);
+		memcpy(bp.data, build_payload, n_build * 4);
+		join.SinkBuildSide({bk, bo}, {bp}, n_build);
+		auto state = join.GetOperatorState(ec);
+		uint64_t n_out = 0;
+		for (uint64_t base = 0; base < n_probe; base += STANDARD_VECTOR_SIZE) {
+			const idx_t n = std::min<idx_t>(STANDARD_VECTOR_SIZE, n_probe - base);
+			DataChunk input, chunk;
+			input.Initialize({LogicalType::INTEGER(), LogicalType::INTEGER()});
+			memcpy(input.data[0].data, probe_keys + base, n * 4);
+			memcpy(input.data[1].data, probe_other + base, n * 4);
+			input.SetCardinality(n);
+			for (;;) {
+				chunk.Initialize(join.types);
+				auto r = join.Execute(ec, input, chunk, *join.op_state, *state);
+				if (r == OperatorResultType::FINISHED) {
+					break;
+				}
+				for (idx_t i = 0; i < chunk.size(); i++) {
+					if (n_out < out_cap) {
+						out_probe_row[n_out] = (uint32_t)(base + chunk.data[0].sel.get_index(i));
+						memcpy(&out_payload[n_out], chunk.data[2].Cell(i), 4);
+					}
+					n_out++;
+				}
+				if (r == OperatorResultType::NEED_MORE_INPUT) {
+					break;
+				}
+			}
+		}
+		return (int64_t)n_out;
+	} catch (std::exception &e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+
 } // extern "C"

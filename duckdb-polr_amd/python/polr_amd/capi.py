@@ -14,6 +14,8 @@ _ROOT = os.path.dirname(os.path.dirname(_PKG))  # duckdb-polr_amd/
 LIB_PATH = os.path.join(_ROOT, "libpolr_hip.so")
 
 MAX_JOINS, MAX_PATHS, MAX_KEYS = 8, 32, 4
+MAX_PREDS = 4
+CMP_PRED = {"<>": 1, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5}
 COL_SIGNED, COL_DEVICE = 1, 2
 
 OK, E_NO_DEVICE, E_INVALID, E_UNSUPPORTED, E_HIP, E_DUPLICATE, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6
@@ -47,7 +49,9 @@ class Col(C.Structure):
 
 class JoinDesc(C.Structure):
     _fields_ = [("ht", C.c_void_p), ("n_keys", C.c_uint32), ("key_src_join", C.c_int32 * MAX_KEYS),
-                ("key_src_col", C.c_int32 * MAX_KEYS)]
+                ("key_src_col", C.c_int32 * MAX_KEYS), ("n_preds", C.c_uint32), ("pred_op", C.c_uint32 * MAX_PREDS),
+                ("pred_src_join", C.c_int32 * MAX_PREDS), ("pred_src_col", C.c_int32 * MAX_PREDS),
+                ("pred_build_col", C.c_uint32 * MAX_PREDS)]
 
 
 class Round(C.Structure):
@@ -343,6 +347,15 @@ class Pipeline:
             for c, (sj, sc) in enumerate(key_src):
                 jd[i].key_src_join[c] = sj
                 jd[i].key_src_col[c] = sc
+            # non-equality conditions of the join ride on the table object: ht.preds = [(op, (src_join, src_col),
+            # payload column index)] (build_joins sets it from the workload's "preds")
+            preds = getattr(ht, "preds", None) or []
+            jd[i].n_preds = len(preds)
+            for c, (op, (sj, sc), bc) in enumerate(preds[:MAX_PREDS]):
+                jd[i].pred_op[c] = CMP_PRED[op] if isinstance(op, str) else op
+                jd[i].pred_src_join[c] = sj
+                jd[i].pred_src_col[c] = sc
+                jd[i].pred_build_col[c] = bc
         paths = np.ascontiguousarray(np.asarray(paths, dtype=np.int32).reshape(-1, self.k))
         self.n_paths = len(paths)
         h = C.c_void_p()
@@ -709,5 +722,7 @@ def build_joins(ctx, wl, auto=False):
             done = ht.finalize_perfect(*j["perfect"])
         if not done:
             ht.finalize_hash()
+        names = list(j["payload"].keys())
+        ht.preds = [(op, src, names.index(col)) for op, src, col in j.get("preds", [])]
         joins.append((ht, j["key_src"]))
     return joins

@@ -208,3 +208,27 @@ def hash_join_probe(ctx, build_keys, build_payload, probe_keys, probe_valid=None
     if n > cap:
         raise RuntimeError("output larger than the test buffer")
     return rows[:n].copy(), pay[:n].copy(), calls.value
+
+
+COMPARISON = {"<>": 26, "<": 27, ">": 28, "<=": 29, ">=": 30}  # ExpressionType, expression_type.hpp:34-46
+
+
+def hash_join_probe_cond(ctx, build_keys, build_other, build_payload, op, probe_keys, probe_other):
+    """PhysicalHashJoin with conditions [probe_keys = build_keys, probe_other OP build_other], chunk by chunk"""
+    L = load()
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (build_keys, build_other, build_payload, probe_keys,
+                                                              probe_other)]
+    bk, bo, bp, pk, po = arrs
+    cap = max(1024, 64 * len(pk))
+    rows = np.zeros((cap,), dtype=np.uint32)
+    pay = np.zeros((cap,), dtype=np.int32)
+    L.polr_host_hash_join_probe_cond.restype = C.c_int64
+    L.polr_host_hash_join_probe_cond.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_int] + [C.c_void_p] * 2 + \
+        [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    n = L.polr_host_hash_join_probe_cond(ctx.h, bk.ctypes.data, bo.ctypes.data, bp.ctypes.data, len(bk), COMPARISON[op],
+                                         pk.ctypes.data, po.ctypes.data, len(pk), rows.ctypes.data, pay.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError(L.polr_host_last_error().decode())
+    if n > cap:
+        raise RuntimeError("output larger than the test buffer")
+    return rows[:n].copy(), pay[:n].copy()

@@ -90,6 +90,28 @@ def star_skew(n_fact=200_000, seed=SEED, n_phases=4, dims=((60_000, 37, 0), (2_0
 
 
 # -------------------------------------------------------------------------------------------------
+# star with non-equality conditions next to the equalities (JoinCondition::comparison other than EQUAL: evaluated by
+# RowOperations::Match on every candidate pair, join_hashtable.cpp:455-464).  "preds" = [(op, (src_join, src_col),
+# payload column name)]: left OP right, the right side a column of the join's build side
+# -------------------------------------------------------------------------------------------------
+def star_pred(n_fact=120_000, seed=SEED):
+    wl = star_skew(n_fact=n_fact, seed=seed)
+    rng = _rng(seed, 7)
+    wl["name"] = "star_pred"
+    fact = wl["probe"]["cols"]
+    fact["v"] = rng.integers(-60, 300, n_fact).astype(np.int16)
+    fact["u"] = rng.integers(0, 15_000, n_fact).astype(np.int32)
+    names = list(fact.keys())
+    j0, j1, j2 = wl["joins"]
+    j0["preds"] = [("<", (-1, names.index("v")), "q0")]                                        # fact.v < d0.q0
+    j1["preds"] = [(">=", (-1, names.index("u")), "p1")]                                       # fact.u >= d1.p1
+    j2["preds"] = [("<>", (-1, names.index("v")), "q2"), ("<=", (-1, names.index("u")), "p2")]  # two on one join
+    for j in wl["joins"]:
+        j["perfect"] = None  # a join with more than one condition is never a perfect-hash join
+    return wl
+
+
+# -------------------------------------------------------------------------------------------------
 # dependent chain: join 1 probes with a column that join 0's build side provides
 # (left_expression_bindings, polar_config.cpp:152-229); join 2 is independent
 # -------------------------------------------------------------------------------------------------

@@ -171,11 +171,22 @@ void polr_comm_destroy(polr_comm *comm);
  * the joins of the run, where each join reads its probe key (a probe-table column, or a build
  * column of an earlier join: left_expression_bindings, :152-229) and the candidate join orders.
  * ------------------------------------------------------------------------------------------- */
+#define POLR_MAX_PREDS 4 /* non-equality conditions per join */
 typedef struct polr_join_desc {
 	polr_ht *ht;
 	uint32_t n_keys;
 	int32_t key_src_join[POLR_MAX_KEYS]; /* -1 = probe-table column, j >= 0 = payload column of join j */
 	int32_t key_src_col[POLR_MAX_KEYS];
+	/* the join's conditions other than equalities (JoinCondition::comparison; JoinHashTable::predicates,
+	 * join_hashtable.cpp:50-52; RowOperations::Match, row_match.cpp:59-119): `left OP right` with the left side read
+	 * like a key (pred_src_*) and the right side a payload column of this join's build side; a NULL on either side
+	 * never matches; both sides must have the same width.  The join's output (and its share of the intermediates)
+	 * are the pairs that pass. */
+	uint32_t n_preds;
+	uint32_t pred_op[POLR_MAX_PREDS]; /* POLR_CMP_NE .. POLR_CMP_GE */
+	int32_t pred_src_join[POLR_MAX_PREDS];
+	int32_t pred_src_col[POLR_MAX_PREDS];
+	uint32_t pred_build_col[POLR_MAX_PREDS];
 } polr_join_desc;
 
 int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_probe_cols, uint64_t n_probe_rows,

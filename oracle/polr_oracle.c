@@ -106,7 +106,7 @@ void orc_free(void *p) {
 struct orc_ht {
 	int n_keys, n_payload;
 	int key_width[ORC_MAX_KEYS], key_signed[ORC_MAX_KEYS];
-	int payload_width[64];
+	int payload_width[64], payload_signed[64];
 	idx_t offsets[ORC_MAX_KEYS + 64 + 1]; /* keys, payload, hash slot */
 	idx_t flag_width, row_width, pointer_offset;
 	idx_t count, capacity, bitmask;
@@ -152,6 +152,7 @@ orc_ht_t *orc_ht_build(const orc_col_t *keys, int n_keys, const orc_col_t *paylo
 	}
 	for (int i = 0; i < n_payload; i++) {
 		ht->payload_width[i] = payload[i].width;
+		ht->payload_signed[i] = payload[i].is_signed;
 		ht->offsets[n_keys + i] = w;
 		w += (idx_t)payload[i].width;
 	}
@@ -943,6 +944,91 @@ static const uint8_t *key_cell(const exec_t *e, const int32_t *path, const chunk
 	return row + sj->ht->offsets[lcol];
 }
 
+/* left side of predicate c of join join_idx for tuple t (same sources as the equality keys) */
+static const uint8_t *pred_cell(const exec_t *e, const int32_t *path, const chunk_t *chunk, idx_t t, int join_idx,
+                                int c, int *valid) {
+	const orc_join_t *j = &e->joins[join_idx];
+	int src = j->pred_src_join[c];
+	int col = j->pred_src_col[c];
+	if (src < 0) {
+		const orc_col_t *pc = &e->probe_cols[col];
+		idx_t row = chunk->cols[0][t];
+		*valid = pc->valid ? pc->valid[row] : 1;
+		return (const uint8_t *)pc->data + row * (idx_t)pc->width;
+	}
+	int pos = -1;
+	for (int q = 0; q < e->k; q++) {
+		if (path[q] == src) {
+			pos = q;
+			break;
+		}
+	}
+	const orc_join_t *sj = &e->joins[src];
+	idx_t id = chunk->cols[1 + pos][t];
+	idx_t ht_row = sj->pht ? sj->pht->ht_row[id] : id;
+	const uint8_t *row = sj->ht->rows + ht_row * sj->ht->row_width;
+	int lcol = sj->ht->n_keys + col;
+	*valid = row_col_valid(sj->ht, row, lcol);
+	return row + sj->ht->offsets[lcol];
+}
+
+static int64_t cell_i64(const uint8_t *p, int width, int is_signed) {
+	switch (width) {
+	case 1:
+		return is_signed ? (int64_t) * (const int8_t *)p : (int64_t)*p;
+	case 2: {
+		uint16_t v;
+		memcpy(&v, p, 2);
+		return is_signed ? (int64_t)(int16_t)v : (int64_t)v;
+	}
+	case 4: {
+		uint32_t v;
+		memcpy(&v, p, 4);
+		return is_signed ? (int64_t)(int32_t)v : (int64_t)v;
+	}
+	default: {
+		int64_t v;
+		memcpy(&v, p, 8);
+		return v;
+	}
+	}
+}
+
+/* TemplatedMatchType<T, OP> (row_match.cpp:59-119): both sides valid and `left OP right` (a NULL on either side never
+ * matches); 8-byte unsigned columns compare as unsigned */
+static int pred_holds(int op, const uint8_t *l, const uint8_t *r, int width, int is_signed) {
+	if (width == 8 && !is_signed) {
+		uint64_t a, b;
+		memcpy(&a, l, 8);
+		memcpy(&b, r, 8);
+		switch (op) {
+		case ORC_CMP_NE:
+			return a != b;
+		case ORC_CMP_LT:
+			return a < b;
+		case ORC_CMP_GT:
+			return a > b;
+		case ORC_CMP_LE:
+			return a <= b;
+		default:
+			return a >= b;
+		}
+	}
+	const int64_t a = cell_i64(l, width, is_signed), b = cell_i64(r, width, is_signed);
+	switch (op) {
+	case ORC_CMP_NE:
+		return a != b;
+	case ORC_CMP_LT:
+		return a < b;
+	case ORC_CMP_GT:
+		return a > b;
+	case ORC_CMP_LE:
+		return a <= b;
+	default:
+		return a >= b;
+	}
+}
+
 /* ScanStructure::NextInnerJoin (join_hashtable.cpp:531-565) with ScanInnerJoin (:466-487),
  * ResolvePredicates/RowOperations::Match for equality keys (:455-464, row_match.cpp:59-119),
  * AdvancePointers (:489-501).  At most one match per probe tuple per call. */
@@ -968,6 +1054,16 @@ static void next_inner_join(exec_t *e, const int32_t *path, int pos, join_state_
 				/* TemplatedMatchType<T, Equals, NO_MATCH_SEL=false>: row validity bit && equal */
 				if (!valid || !row_col_valid(ht, row, c) ||
 				    memcmp(cell, row + ht->offsets[c], (size_t)ht->key_width[c]) != 0) {
+					match = 0;
+				}
+			}
+			for (int c = 0; c < j->n_preds && match; c++) {
+				int valid;
+				const uint8_t *cell = pred_cell(e, path, left, idx, join_idx, c, &valid);
+				const int lcol = ht->n_keys + j->pred_build_col[c];
+				if (!valid || !row_col_valid(ht, row, lcol) ||
+				    !pred_holds(j->pred_op[c], cell, row + ht->offsets[lcol], ht->payload_width[j->pred_build_col[c]],
+				                ht->payload_signed[j->pred_build_col[c]])) {
 					match = 0;
 				}
 			}

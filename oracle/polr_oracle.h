@@ -25,6 +25,7 @@ typedef uint64_t idx_t;
 #define ORC_MAX_JOINS 16
 #define ORC_MAX_PATHS 64
 #define ORC_MAX_KEYS 4
+#define ORC_MAX_PREDS 4
 #define ORC_MAX_VECTOR 2048
 
 /* MultiplexerRouting, src/include/duckdb/main/config.hpp:41-50 (same order) */
@@ -104,7 +105,16 @@ typedef struct orc_join {
 	int32_t key_src_join[ORC_MAX_KEYS]; /* -1: probe-table column; j>=0: payload column of join j */
 	int32_t key_src_col[ORC_MAX_KEYS];
 	idx_t estimated_cardinality; /* for the min-card enumerators */
+	/* non-equality conditions of the join (JoinHashTable::predicates, join_hashtable.cpp:50-52): evaluated by
+	 * RowOperations::Match together with the equalities (row_match.cpp:59-119, 141-263); the right-hand side is a
+	 * column the build side carries (here: payload column pred_build_col of this join's table) */
+	int32_t n_preds;
+	int32_t pred_op[ORC_MAX_PREDS];       /* ORC_CMP_NE .. ORC_CMP_GE (below): left OP right */
+	int32_t pred_src_join[ORC_MAX_PREDS]; /* left side, as key_src_join / key_src_col */
+	int32_t pred_src_col[ORC_MAX_PREDS];
+	int32_t pred_build_col[ORC_MAX_PREDS];
 } orc_join_t;
+
 
 typedef struct orc_config {
 	int32_t routing;

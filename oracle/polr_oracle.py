@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpolr_oracle.so")
 
 MAX_JOINS, MAX_PATHS, MAX_KEYS = 16, 64, 4
+MAX_PREDS = 4
+CMP_PRED = {"<>": 1, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5}
 
 ROUTING = {
     "alternate": 0, "adaptive_reinit": 1, "dynamic": 2, "init_once": 3, "opportunistic": 4,
@@ -40,7 +42,9 @@ class _Col(C.Structure):
 class _Join(C.Structure):
     _fields_ = [("ht", C.c_void_p), ("pht", C.c_void_p), ("n_keys", C.c_int32),
                 ("key_src_join", C.c_int32 * MAX_KEYS), ("key_src_col", C.c_int32 * MAX_KEYS),
-                ("estimated_cardinality", C.c_uint64)]
+                ("estimated_cardinality", C.c_uint64), ("n_preds", C.c_int32), ("pred_op", C.c_int32 * MAX_PREDS),
+                ("pred_src_join", C.c_int32 * MAX_PREDS), ("pred_src_col", C.c_int32 * MAX_PREDS),
+                ("pred_build_col", C.c_int32 * MAX_PREDS)]
 
 
 class _Config(C.Structure):
@@ -252,10 +256,15 @@ class JoinSpec:
     """One multiplexed join: `ht` plus where each probe key comes from: (-1, probe col) or
     (join j, payload col of j)."""
 
-    def __init__(self, ht, key_src, estimated_cardinality=0):
+    def __init__(self, ht, key_src, estimated_cardinality=0, preds=()):
+        """preds: non-equality conditions [(op, (src_join, src_col), build payload column index)]: left OP right"""
         self.ht = ht
         self.key_src = list(key_src)
         self.estimated_cardinality = estimated_cardinality
+        self.preds = list(preds)
+        if self.preds and ht.pht:
+            raise ValueError("a join with non-equality conditions is never a perfect-hash join "
+                             "(physical_hash_join.cpp: conditions.size() == 1)")
 
 
 def _joins_struct(joins):
@@ -268,6 +277,12 @@ def _joins_struct(joins):
             arr[i].key_src_join[c] = sj
             arr[i].key_src_col[c] = sc
         arr[i].estimated_cardinality = j.estimated_cardinality
+        arr[i].n_preds = len(j.preds)
+        for c, (op, (sj, sc), bc) in enumerate(j.preds):
+            arr[i].pred_op[c] = CMP_PRED[op] if isinstance(op, str) else op
+            arr[i].pred_src_join[c] = sj
+            arr[i].pred_src_col[c] = sc
+            arr[i].pred_build_col[c] = bc
     return arr
 
 

@@ -34,7 +34,9 @@ def oracle_joins(wl):
         ht = orc.HashTable(j["keys"], list(j["payload"].values()), key_valid=j.get("key_valid"), payload_valid=pv)
         if j.get("perfect") is not None:
             ht.make_perfect(*j["perfect"])
-        joins.append(orc.JoinSpec(ht, j["key_src"], estimated_cardinality=len(j["keys"][0])))
+        names = list(j["payload"].keys())
+        preds = [(op, src, names.index(col)) for op, src, col in j.get("preds", [])]
+        joins.append(orc.JoinSpec(ht, j["key_src"], estimated_cardinality=len(j["keys"][0]), preds=preds))
     return pcols, pvalid, joins
 
 

@@ -81,6 +81,13 @@ def workload_sql(wl, select="*"):
                 src = wl["joins"][sj]
                 left = "%s.%s" % (src["name"], list(src["payload"].keys())[sc])
             conds.append("%s = %s.%s" % (left, j["name"], kn))
+        for op, (sj, sc), col in j.get("preds", []):
+            if sj < 0:
+                left = "%s.%s" % (probe, pcols[sc])
+            else:
+                src = wl["joins"][sj]
+                left = "%s.%s" % (src["name"], list(src["payload"].keys())[sc])
+            conds.append("%s %s %s.%s" % (left, op, j["name"], col))
         sql += " JOIN %s ON %s" % (j["name"], " AND ".join(conds))
         out_cols += ["%s.%s" % (j["name"], c) for c in j["payload"].keys()]
     if select == "*":
@@ -172,6 +179,7 @@ SCENARIOS = {
     "star_skew_nulls": lambda: workloads.star_skew(n_fact=60_000, with_nulls=True),
     "chain_dep": lambda: workloads.chain_dep(),
     "fanout": lambda: workloads.fanout(),
+    "star_pred": lambda: workloads.star_pred(),
 }
 
 ROUTINGS = ["init_once", "opportunistic", "adaptive_reinit", "dynamic", "exponential_backoff", "default_path"]

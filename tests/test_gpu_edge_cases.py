@@ -16,9 +16,13 @@ def run_both(ctx, probe_cols, joins_spec, paths, probe_valid=None, emit=True):
     """joins_spec: [(keys, payload, key_src, perfect, key_valid)] -> (gpu counts per path, gpu ids, oracle out_rows)"""
     k = len(joins_spec)
     ojoins, gjoins = [], []
-    for keys, payload, key_src, perfect, key_valid in joins_spec:
-        oht = orc.HashTable(keys, payload, key_valid=key_valid)
-        ght = capi.HashTable.from_columns(ctx, keys, payload, key_valid=key_valid)
+    for spec in joins_spec:
+        keys, payload, key_src, perfect, key_valid = spec[:5]
+        preds = list(spec[5]) if len(spec) > 5 else []       # [(op, (src_join, src_col), payload index)]
+        payload_valid = spec[6] if len(spec) > 6 else None
+        oht = orc.HashTable(keys, payload, key_valid=key_valid, payload_valid=payload_valid)
+        ght = capi.HashTable.from_columns(ctx, keys, payload, key_valid=key_valid, payload_valid=payload_valid)
+        ght.preds = preds
         done = False
         if perfect is not None:
             if oht.make_perfect(*perfect):
@@ -28,7 +32,7 @@ def run_both(ctx, probe_cols, joins_spec, paths, probe_valid=None, emit=True):
                 assert not ght.finalize_perfect(*perfect)  # both sides detect the duplicate
         if not done:
             ght.finalize_hash()
-        ojoins.append(orc.JoinSpec(oht, key_src))
+        ojoins.append(orc.JoinSpec(oht, key_src, preds=preds))
         gjoins.append((ght, key_src))
     n = len(probe_cols[0])
     pipe = capi.Pipeline(ctx, probe_cols, n, gjoins, paths, probe_valid=probe_valid)
@@ -329,3 +333,35 @@ def test_composite_key_wider_than_64_bits_is_refused(gpu_ctx):
     with pytest.raises(capi.PolrError) as e:
         capi.HashTable.from_columns(gpu_ctx, keys + keys[:2], [])
     assert e.value.code == capi.E_UNSUPPORTED
+
+
+def test_non_equality_conditions(gpu_ctx):
+    """join conditions other than equalities (RowOperations::Match, row_match.cpp:59-119): every operator, signed and
+    unsigned sides, 64-bit unsigned values beyond 2^63, NULLs on either side, and a left side that is a build column of
+    the join before it"""
+    rng = np.random.default_rng(51)
+    n_b, n_p = 4000, 15000
+    bk = rng.integers(0, 600, n_b).astype(np.int32)  # repeated keys: several candidate rows per probe tuple
+    pk = rng.integers(0, 640, n_p).astype(np.int32)
+    for dt, lo, hi in ((np.int8, -100, 100), (np.uint16, 0, 60000), (np.int64, -2**50, 2**50),
+                       (np.uint64, 2**63 - 1000, 2**63 + 1000)):
+        bw = rng.integers(lo, hi, n_b, dtype=np.int64 if dt != np.uint64 else np.uint64).astype(dt)
+        pv = rng.integers(lo, hi, n_p, dtype=np.int64 if dt != np.uint64 else np.uint64).astype(dt)
+        pv[:50] = bw[:50]  # some equal pairs (<= / >= / <> differ from < / > only there)
+        for op in ("<", ">", "<=", ">=", "<>"):
+            run_both(gpu_ctx, [pk, pv], [([bk], [bw], [(-1, 0)], None, None, [(op, (-1, 1), 0)])], [[0]])
+    # NULLs: a NULL left or right side never matches
+    bw = rng.integers(-50, 50, n_b).astype(np.int16)
+    pv = rng.integers(-50, 50, n_p).astype(np.int16)
+    bw_valid = (rng.random(n_b) > 0.1).astype(np.uint8)
+    pv_valid = (rng.random(n_p) > 0.1).astype(np.uint8)
+    run_both(gpu_ctx, [pk, pv], [([bk], [bw], [(-1, 0)], None, None, [("<", (-1, 1), 0)], [bw_valid])], [[0]],
+             probe_valid=[None, pv_valid])
+    # left side = payload column 0 of join 0, two conditions on join 1; both join orders that respect the dependency
+    k0 = np.arange(500, dtype=np.int32)
+    w0 = rng.integers(-50, 50, 500).astype(np.int16)
+    p0 = rng.integers(0, 520, n_p).astype(np.int32)
+    rows = run_both(gpu_ctx, [p0, pk, pv],
+                    [([k0], [w0], [(-1, 0)], None, None),
+                     ([bk], [bw], [(-1, 1)], None, None, [(">=", (0, 0), 0), ("<>", (-1, 2), 0)])], [[0, 1]])
+    assert rows > 0

@@ -73,3 +73,24 @@ def test_physical_hash_join_execute_protocol(gpu_ctx, perfect):
         assert calls == n_chunks  # one Execute per chunk, NEED_MORE_INPUT (perfect_hash_join_executor.cpp:207)
     else:
         assert calls >= 2 * n_chunks  # >= 2 Execute calls per probed chunk (SURVEY 3.4 ii)
+
+
+@pytest.mark.parametrize("op", ["<", ">=", "<>"])
+def test_physical_hash_join_with_a_non_equality_condition(gpu_ctx, op):
+    """conditions [=, OP] on the operator-level drop-in: the equality keys the table, the other condition is evaluated
+    on every candidate pair (JoinHashTable::predicates); its build column is not part of the output"""
+    rng = np.random.default_rng(12)
+    bk = np.repeat(np.arange(0, 3000, 7, dtype=np.int32), rng.integers(1, 6, size=429))
+    bo = rng.integers(-40, 40, len(bk)).astype(np.int32)
+    bp = (np.arange(len(bk), dtype=np.int32) * 3) % 1009
+    pk = rng.integers(0, 3100, 6000).astype(np.int32)
+    po = rng.integers(-40, 40, 6000).astype(np.int32)
+    rows, pay = host.hash_join_probe_cond(gpu_ctx, bk, bo, bp, op, pk, po)
+    ht = orc.HashTable([bk], [bp, bo])
+    ref = orc.run_pipeline([pk, po], [orc.JoinSpec(ht, [(-1, 0)], preds=[(op, (-1, 1), 1)])], [[0]],
+                           routing="default_path")
+    want = ref["out_rows"]
+    want_pairs = np.stack([want[:, 0], bp[want[:, 1]].astype(np.uint32)], 1)
+    got_pairs = np.stack([rows, pay.astype(np.uint32)], 1)
+    assert len(got_pairs) == len(want_pairs) > 0
+    assert np.array_equal(got_pairs[np.lexsort(got_pairs.T[::-1])], want_pairs[np.lexsort(want_pairs.T[::-1])])

@@ -19,6 +19,7 @@ SCENARIOS = {
     "star_skew_nulls": lambda: workloads.star_skew(n_fact=60_000, with_nulls=True),
     "chain_dep": lambda: workloads.chain_dep(),
     "fanout": lambda: workloads.fanout(),
+    "star_pred": lambda: workloads.star_pred(),
 }
 _cache = {}
 
