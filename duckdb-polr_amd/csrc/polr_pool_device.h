@@ -11,21 +11,26 @@
 // the grid, and a skewed source range only makes its executor finish later, not its share of the device.
 //
 //   rings     POLR_POOL_RINGS (64) x {hi, mid, lo}: FIFO of 16-byte unit entries.  Probe wave g of the pool uses ring
-//             g % 64 (every ring the same number of waves); three queues per ring, see PoolRoundOut (64 rings keep the
-//             pollers of one control line few: with 8 rings, 512 idle waves per ring answered
-//             every small round with a storm of compare-and-swaps on one word -- measured 8 us per round, serialised over
-//             all executors).  Routers deal the units of a round round-robin over the rings.  hi = rounds of <= POLR_POOL_HI_TUPLES tuples (exploration
-//             slices: latency-critical, taken first), lo = everything else.
+//             g % 64 (every ring the same number of waves).  64 rings keep the pollers of one control line few: with
+//             8 rings, 512 idle waves per ring answered every small round with a storm of compare-and-swaps on one word
+//             -- measured 8 us per round, serialised over all executors.  Routers deal the units of a round round-robin
+//             over the rings.  hi = rounds of <= POLR_POOL_HI_TUPLES tuples (exploration slices: latency-critical,
+//             taken first), mid = bigger rounds whose counters their executor waits for, lo = terminal rounds
+//             (PoolRoundOut).
 //   entry     two 8-byte granules, each carrying the lap tag of its ticket, written and read with relaxed
 //             agent-scope 8-byte atomics (self-validating, no fences):
-//               g0 = tag:16 | kind:2 | slot:1 | emit:1 | path:5 | 0:7 | begin:32
+//               g0 = tag:16 | kind:2 | slot:2 | emit:1 | path:5 | 0:6 | begin:32
 //               g1 = tag:16 | exec:16 | count:32
-//   tickets   lo: a wave takes the next ticket with one returning atomicAdd on lo_head and waits for the entry of
-//             that ticket (tickets past lo_tail are simply not written yet); hi: never waited on -- taken with a CAS
-//             on hi_head only while hi_head < hi_tail.  heads/tails are monotonic across runs (tags never repeat
-//             within 65535 laps).
-//   arrival   a wave adds its k stage counters to the executor's bank [slot][ring][k] with returning atomics, then
-//             1 to arrived[slot][ring]; the router waits for the sum of the 8 shards to reach the units it has
+//   tickets   mid, lo: a wave takes the next ticket with one returning atomic add on the queue's head and looks for the
+//             entry of that ticket (tickets past the tail are simply not written yet; it keeps the ticket while it
+//             serves other queues); hi: never waited on -- taken with a CAS on hi_head only while hi_head < hi_tail,
+//             and only by the waves whose number matches the ticket's in the low `lottery` bits.  heads/tails are
+//             monotonic across runs (tags never repeat within 65535 laps).
+//   slots     POLR_SLOTS (4) rounds of one executor can be in flight: the front one decided, the others rehearsed
+//             ahead on a shadow of the state while their decisions cannot depend on intermediates still outstanding
+//             (polr_can_speculate); each slot has its own counter bank and arrival counters.
+//   arrival   a wave adds its k stage counters to the executor's bank [slot][ring & 7][k] with returning atomics, then
+//             1 to arrived[slot][ring & 7]; the router waits for the sum of the 8 shards to reach the units it has
 //             published in that slot, exchanges the counters with 0 and routes.
 //   exit      the router that finishes last publishes one EXIT entry per worker wave of every ring (lo).
 //   watchdog  every wait is bounded (POLR_RES_TIMEOUT_TICKS); a timeout raises `abort` in the run header, which every
