@@ -1005,8 +1005,24 @@ static void fill_dev_join(DevJoin *dj, const polr_join_desc *jd, const polr_ht *
 }
 
 // resolve every (join order, position) of a pipeline variant into a StageDesc (see polr_device.h)
-static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std::vector<StageDesc> &out) {
+// ext: extension records of the stages that need one (appended; StageDesc::ext holds the INDEX + 1 until the records
+// have their device address, see polr_pipeline_create)
+static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std::vector<StageDesc> &out,
+                              std::vector<StageExt> &ext) {
 	out.assign((size_t)dp.n_paths * POLR_KMAX, StageDesc());
+	auto source = [&](int32_t sj, int32_t sc, int32_t &slot, const uint8_t *&data, const uint8_t *&valid) {
+		if (sj < 0) {
+			slot = 0;
+			data = p->probe_cols[sc].data;
+			valid = p->probe_cols[sc].valid;
+		} else {
+			const polr_ht *src = p->hts[sj];
+			const OwnedCol &col = src->kind == KIND_PERFECT ? src->pcols[sc] : src->payload[sc];
+			slot = dp.slot_of_join[sj];
+			data = col.data;
+			valid = col.valid;
+		}
+	};
 	for (uint32_t q = 0; q < dp.n_paths; q++) {
 		for (uint32_t pos = 0; pos < dp.k; pos++) {
 			const uint32_t j = dp.paths[q].order[pos];
@@ -1018,44 +1034,33 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 			d.n_keys = dj.n_keys;
 			d.key_signed = dj.key_signed;
 			d.out_slot = dp.slot_of_join[j];
-			for (uint32_t c = 0; c < dj.n_keys; c++) {
+			for (uint32_t c = 0; c < dj.n_keys && c < 2; c++) {
 				d.key_width[c] = dj.key_width[c];
-				const int32_t sj = dj.key_src_join[c];
-				const int32_t sc = dj.key_src_col[c];
-				if (sj < 0) {
-					d.key_slot[c] = 0;
-					d.key_data[c] = p->probe_cols[sc].data;
-					d.key_valid[c] = p->probe_cols[sc].valid;
-				} else {
-					const polr_ht *src = p->hts[sj];
-					const OwnedCol &col = src->kind == KIND_PERFECT ? src->pcols[sc] : src->payload[sc];
-					d.key_slot[c] = dp.slot_of_join[sj];
-					d.key_data[c] = col.data;
-					d.key_valid[c] = col.valid;
-				}
+				source(dj.key_src_join[c], dj.key_src_col[c], d.key_slot[c], d.key_data[c], d.key_valid[c]);
 			}
-			d.pack = ht->pack;
+			d.packed = ht->pack.packed;
 			d.n_preds = dj.n_preds;
-			for (uint32_t c = 0; c < dj.n_preds; c++) {
-				const int32_t sj = dj.pred_src_join[c];
-				const int32_t sc = dj.pred_src_col[c];
-				const OwnedCol &bcol = ht->kind == KIND_PERFECT ? ht->pcols[dj.pred_build_col[c]] : ht->payload[dj.pred_build_col[c]];
-				d.pred_op[c] = dj.pred_op[c];
-				d.pred_width[c] = bcol.width;
-				d.pred_sx[c] = (bcol.flags & 1u) ? 1u : 0u;
-				d.pred_bdata[c] = bcol.data;
-				d.pred_bvalid[c] = bcol.valid;
-				if (sj < 0) {
-					d.pred_slot[c] = 0;
-					d.pred_data[c] = p->probe_cols[sc].data;
-					d.pred_valid[c] = p->probe_cols[sc].valid;
-				} else {
-					const polr_ht *src = p->hts[sj];
-					const OwnedCol &col = src->kind == KIND_PERFECT ? src->pcols[sc] : src->payload[sc];
-					d.pred_slot[c] = dp.slot_of_join[sj];
-					d.pred_data[c] = col.data;
-					d.pred_valid[c] = col.valid;
+			if (d.packed || d.n_preds) {
+				StageExt x;
+				memset(&x, 0, sizeof(x));
+				for (uint32_t c = 0; c < dj.n_keys; c++) {
+					x.key_width[c] = dj.key_width[c];
+					source(dj.key_src_join[c], dj.key_src_col[c], x.key_slot[c], x.key_data[c], x.key_valid[c]);
 				}
+				x.pack = ht->pack;
+				x.n_preds = dj.n_preds;
+				for (uint32_t c = 0; c < dj.n_preds; c++) {
+					const OwnedCol &bcol =
+					    ht->kind == KIND_PERFECT ? ht->pcols[dj.pred_build_col[c]] : ht->payload[dj.pred_build_col[c]];
+					x.pred_op[c] = dj.pred_op[c];
+					x.pred_width[c] = bcol.width;
+					x.pred_sx[c] = (bcol.flags & 1u) ? 1u : 0u;
+					x.pred_bdata[c] = bcol.data;
+					x.pred_bvalid[c] = bcol.valid;
+					source(dj.pred_src_join[c], dj.pred_src_col[c], x.pred_slot[c], x.pred_data[c], x.pred_valid[c]);
+				}
+				ext.push_back(x);
+				d.ext = (const StageExt *)(uintptr_t)ext.size(); // index + 1, patched to the device address later
 			}
 			d.table = ht->table;
 			d.rowids = ht->rowids;
@@ -1331,10 +1336,25 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 		}
 		c.W = w;
 		std::vector<StageDesc> sd_mat, sd_count;
-		build_stage_descs(p, p->host_mat, sd_mat);
-		build_stage_descs(p, p->host_count, sd_count);
+		std::vector<StageExt> sd_ext;
+		build_stage_descs(p, p->host_mat, sd_mat, sd_ext);
+		build_stage_descs(p, p->host_count, sd_count, sd_ext);
 		plan_flat(p, sd_count);
-		hipError_t e = hipMalloc((void **)&p->stages_mat, sd_mat.size() * sizeof(StageDesc));
+		p->host_mat.ext = p->host_count.ext = sd_ext.empty() ? 0u : 1u;
+		hipError_t e = hipSuccess;
+		if (!sd_ext.empty()) {
+			e = hipMalloc((void **)&p->stage_ext, sd_ext.size() * sizeof(StageExt));
+			e = e == hipSuccess ? hipMemcpy(p->stage_ext, sd_ext.data(), sd_ext.size() * sizeof(StageExt), hipMemcpyHostToDevice)
+			                    : e;
+			for (auto *sd : {&sd_mat, &sd_count}) {
+				for (auto &d : *sd) {
+					if (d.ext) {
+						d.ext = p->stage_ext + ((uintptr_t)d.ext - 1);
+					}
+				}
+			}
+		}
+		e = e == hipSuccess ? hipMalloc((void **)&p->stages_mat, sd_mat.size() * sizeof(StageDesc)) : e;
 		e = e == hipSuccess ? hipMalloc((void **)&p->stages_count, sd_count.size() * sizeof(StageDesc)) : e;
 		e = e == hipSuccess ? hipMemcpy(p->stages_mat, sd_mat.data(), sd_mat.size() * sizeof(StageDesc),
 		                                hipMemcpyHostToDevice)
@@ -1470,6 +1490,9 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	}
 	if (p->dev_count) {
 		hipFree(p->dev_count);
+	}
+	if (p->stage_ext) {
+		hipFree(p->stage_ext);
 	}
 	if (p->stages_mat) {
 		hipFree(p->stages_mat);

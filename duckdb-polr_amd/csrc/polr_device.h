@@ -103,28 +103,19 @@ struct DevPath {
 // One join of one join order, fully resolved on the host at pipeline creation so the path kernel
 // needs no pointer chasing: which tuple slot indexes the key column(s), where the key column lives,
 // which index to probe and which tuple slot receives the matched build row.
-struct StageDesc {
-	uint32_t kind;
-	uint32_t n_keys;
+// The uncommon parts of a stage -- composite keys beyond the plain two-column form, non-equality conditions -- live in
+// an extension record in global memory (StageDesc::ext): the descriptor every probe wave keeps in LDS stays small (the
+// per-wave LDS of the generic kernel is K descriptors + the queues, and it is staged again whenever the join order of a
+// unit differs from the last one's).
+struct StageExt {
+	// every key column of the join, in packed form (KeyPack)
 	uint32_t key_width[POLR_NKEYS];
-	uint32_t key_signed;
-	int32_t key_slot[POLR_NKEYS]; // tuple slot whose value indexes key column c (0 = probe row)
-	int32_t out_slot;             // tuple slot that receives this join's build id, -1: not carried
+	int32_t key_slot[POLR_NKEYS];
 	const uint8_t *key_data[POLR_NKEYS];
 	const uint8_t *key_valid[POLR_NKEYS];
-	const void *table;
-	const uint32_t *rowids;
-	uint64_t mask;
-	int64_t min_value;
-	uint64_t range;
-	uint32_t sentinel_start;
-	uint32_t sentinel_count;
-	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1); 2: keys may repeat
-	uint32_t lds_off1; // flat pipelines: 1 + dword offset of this join's bit table in the workgroup's LDS table area; 0 = HBM
-	KeyPack pack;      // composite keys in packed form (read from the descriptor at use: the rare case)
-	// non-equality conditions, evaluated on every (tuple, build row) pair the equalities produce (read from the
-	// descriptor at use): left = column pred_data[c] at the row in tuple slot pred_slot[c], right = build column
-	// pred_bdata[c] at the build id
+	KeyPack pack;
+	// non-equality conditions, evaluated on every (tuple, build row) pair the equalities produce: left = column
+	// pred_data[c] at the row in tuple slot pred_slot[c], right = build column pred_bdata[c] at the build id
 	uint32_t n_preds;
 	uint32_t pred_op[POLR_NPREDS];
 	uint32_t pred_width[POLR_NPREDS];
@@ -136,6 +127,29 @@ struct StageDesc {
 	const uint8_t *pred_bdata[POLR_NPREDS];
 	const uint8_t *pred_bvalid[POLR_NPREDS];
 };
+
+struct StageDesc {
+	uint32_t kind;
+	uint32_t n_keys;
+	uint32_t key_width[2];
+	uint32_t key_signed;
+	int32_t key_slot[2];        // tuple slot whose value indexes key column c (0 = probe row)
+	int32_t out_slot;           // tuple slot that receives this join's build id, -1: not carried
+	const uint8_t *key_data[2]; // (plain form: one key, or two of <= 32 bits; packed composites: StageExt)
+	const uint8_t *key_valid[2];
+	const void *table;
+	const uint32_t *rowids;
+	uint64_t mask;
+	int64_t min_value;
+	uint64_t range;
+	uint32_t sentinel_start;
+	uint32_t sentinel_count;
+	uint32_t unique;   // 1: at most one build row per key (perfect table or longest run == 1); 2: keys may repeat
+	uint32_t lds_off1; // flat pipelines: 1 + dword offset of this join's bit table in the workgroup's LDS table area; 0 = HBM
+	uint32_t packed;   // composite key in packed form: fetch it through ext
+	uint32_t n_preds;  // non-equality conditions: evaluate them through ext
+	const StageExt *ext; // nullptr unless packed or n_preds
+};
 #define STAGE_DESC_DWORDS (sizeof(StageDesc) / 4)
 
 struct DevPipeline {
@@ -144,6 +158,8 @@ struct DevPipeline {
 	uint32_t n_probe_cols;
 	uint32_t W;             // slots carried per tuple: 1 (probe row) + carried build ids
 	uint32_t materialize;   // 1: all build ids carried, slot 1+j = join j
+	uint32_t ext;           // some stage has an extension record (packed composite key, non-equality conditions): POLR_EXT kernels
+	uint32_t ext_pad;
 	int32_t slot_of_join[POLR_KMAX]; // slot index holding join j's build id, or -1
 	const DevCol *probe_cols;
 	const uint32_t *sel;    // nullptr = identity

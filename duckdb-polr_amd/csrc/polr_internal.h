@@ -94,6 +94,7 @@ struct polr_pipeline {
 	DevPipeline host_count, host_mat; // count-only (narrow tuples) and materialising (all ids) variants
 	DevPipeline *dev_count = nullptr, *dev_mat = nullptr;
 	StageDesc *stages_count = nullptr, *stages_mat = nullptr; // [n_paths][POLR_KMAX] each
+	StageExt *stage_ext = nullptr; // extension records of both variants (those stages that have one)
 	int blocks_per_cu_count = 0, blocks_per_cu_mat = 0;       // measured residency of the path kernel
 	uint32_t wpb_count = 0, wpb_mat = 0;                      // waves per workgroup (4, or fewer when the LDS queues are wide)
 	uint32_t flat_wpb = 0;                                    // flat pipelines: waves per workgroup of the flat pool kernel
@@ -155,9 +156,9 @@ hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, ui
 // the whole run in one launch (polr_pool.hip): routers + a pool of probe waves
 struct PoolRun;
 size_t polr_pool_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_per_block);
-int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block);
+int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block, bool ext);
 hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, hipStream_t stream,
-                                   const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run, DevOut out);
+                                   const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run, DevOut out, bool ext);
 size_t polr_pool_flat_lds_bytes(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
 size_t polr_pool_flat_wave_bytes(uint32_t k);
 int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);

@@ -298,7 +298,7 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
 	}
 	memset(info, 0, sizeof(*info));
 	info->waves_per_workgroup = wpb;
-	const int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb);
+	const int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb, dp.ext != 0);
 	info->workgroups_per_cu = (uint32_t)std::max(0, std::min(occ, 8));
 	info->lds_bytes_per_workgroup = (uint32_t)(flat ? polr_pool_flat_lds_bytes(dp.k, wpb, dp.lds_table_dwords)
 	                                                : polr_pool_lds_bytes(dp.k, dp.W, wpb));
@@ -570,7 +570,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	if (wpb == 0) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
 	}
-	int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb);
+	int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb, dp.ext != 0);
 	if (occ < 1) {
 		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel does not fit on a CU");
 	}
@@ -702,6 +702,14 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		}();
 		hr->hi_tuples = hi_env >= 0 ? (uint32_t)std::min<long>(hi_env, POLR_POOL_HI_TUPLES) : POLR_POOL_HI_TUPLES;
 	}
+	{
+		// (tuning knob: POLR_POOL_IDLE_SLEEP = 16 keeps an idle probe wave's back-off at s_sleep 16; default 64)
+		static const long is_env = [] {
+			const char *v = getenv("POLR_POOL_IDLE_SLEEP");
+			return v ? atol(v) : 0l;
+		}();
+		hr->idle_sleep = is_env == 16 ? 16u : 64u;
+	}
 	hr->routers_done = 0;
 	hr->abort = 0;
 	hr->host_words = nullptr;
@@ -763,7 +771,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
 	                                        (PoolRun *)m0->execs_dev)
 	         : polr_launch_pool_kernel(dp.W, dp.k, n_blocks, wpb, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
-	                                   (PoolRun *)m0->execs_dev, dout);
+	                                   (PoolRun *)m0->execs_dev, dout, dp.ext != 0);
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel launch failed: %s", hipGetErrorString(e));
 	}

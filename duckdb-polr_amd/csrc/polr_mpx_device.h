@@ -135,7 +135,7 @@ __device__ __forceinline__ void polr_router_step(DevMpx *mg, DevRound *round, ui
 
 __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, uint64_t *unit_prefix,
                                                   uint32_t *unit_size_out, uint32_t resident_waves,
-                                                  const OffsCache *oc);
+                                                  const OffsCache *oc, bool size_units = true);
 
 // unit = what one wave takes per visit: every wave gets work, never less than `gran` tuples, never more than 2048
 __device__ __forceinline__ void polr_size_units(uint64_t tuples, uint32_t waves, uint64_t gran, uint32_t *unit_size_out,
@@ -208,7 +208,7 @@ __device__ __forceinline__ void polr_router_step_impl(DevMpx *m, DevMpx *mg, Dev
 // been added, Route, fold the routing window, write the round.  m: the state to work on.
 __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, uint64_t *unit_prefix,
                                                   uint32_t *unit_size_out, uint32_t resident_waves,
-                                                  const OffsCache *oc) {
+                                                  const OffsCache *oc, bool size_units) {
 	polr::MultiplexerCore &core = m->core;
 	round->begin = 0;
 	round->count = 0;
@@ -275,8 +275,10 @@ __device__ __forceinline__ void polr_router_route(DevMpx *m, DevRound *round, ui
 	// stage-0 step eats 256 tuples, so units are multiples of 256.  Resident run (the caller passes its
 	// chunk-offset cache): waves are there anyway, a small round is spread 64 tuples per wave -- the dependent-load chain of
 	// a step is the same for 64 and for 256 tuples, so more waves in parallel is strictly faster.
-	const uint64_t gran = (oc == nullptr && ((m->wide0_mask >> path) & 1u)) ? 256 : 64;
-	polr_size_units(tuples, resident_waves, gran, unit_size_out, unit_prefix);
+	if (size_units) { // (the pool cuts its rounds itself: polr_pool_size_units -- four 64-bit divisions saved per step)
+		const uint64_t gran = (oc == nullptr && ((m->wide0_mask >> path) & 1u)) ? 256 : 64;
+		polr_size_units(tuples, resident_waves, gran, unit_size_out, unit_prefix);
+	}
 	polr_publish_progress(m);
 }
 

@@ -19,6 +19,12 @@
 #ifndef POLR_K
 #error "compile with -DPOLR_K=<compiled stage count>"
 #endif
+// Two builds per K: POLR_EXT = 0 (everything; generic stages without their uncommon parts) and POLR_EXT = 1 (the generic
+// kernel only, with packed composite keys and non-equality conditions -- polr_probe_device.h); exported names end in
+// K resp. K'x'
+#ifndef POLR_EXT
+#error "compile with -DPOLR_EXT=0|1"
+#endif
 
 #ifdef POLR_DIAG_TIMELINE
 static __device__ unsigned long long polr_diag_router[16];
@@ -47,7 +53,7 @@ __device__ __forceinline__ void pool_load_run(const PoolRun *run, PoolRun &rh) {
 	rh.units_x = uni(run->units_x);
 	rh.hi_unit = uni(run->hi_unit);
 	rh.hi_lottery = uni(run->hi_lottery);
-	rh.pad = 0;
+	rh.idle_sleep = uni(run->idle_sleep);
 	rh.routers_done = 0;
 	rh.abort = 0;
 	rh.host_words = nullptr;
@@ -162,7 +168,7 @@ __device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const Poo
 	}
 }
 
-template <int W, int K>
+template <int W, int K, int EXT>
 __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__restrict__ pipe,
                                                            const ResidentExec *__restrict__ execs, PoolRun *run,
                                                            DevOut out, uint32_t lds_per_wave) {
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 	uint32_t cur_path = 0xFFFFFFFFu;
 	PoolUnit u;
 	PoolPoller pp;
-	polr_pool_poller_init(pp, run, rh.sync, ring, rh.lo_cap, rh.hi_cap, pool_wave / rh.n_rings, rh.hi_lottery);
+	polr_pool_poller_init(pp, run, rh.sync, ring, rh.lo_cap, rh.hi_cap, pool_wave / rh.n_rings, rh.hi_lottery, rh.idle_sleep);
 	TL_BEGIN(rh.n_router_blocks)
 	while (polr_pool_next_unit(pp, u, c.lane)) {
 		TL_GOT
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(256, 4) void polr_pool_kernel(const DevPipeline *__
 	}
 }
 
+#if !POLR_EXT
 template <int K>
 __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline *__restrict__ pipe,
                                                               const ResidentExec *__restrict__ execs, PoolRun *run,
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 	uint32_t cur_path = 0xFFFFFFFFu;
 	PoolUnit u, nxt;
 	PoolPoller pp;
-	polr_pool_poller_init(pp, run, rh.sync, ring, rh.lo_cap, rh.hi_cap, pool_wave / rh.n_rings, rh.hi_lottery);
+	polr_pool_poller_init(pp, run, rh.sync, ring, rh.lo_cap, rh.hi_cap, pool_wave / rh.n_rings, rh.hi_lottery, rh.idle_sleep);
 	TL_BEGIN(rh.n_router_blocks)
 	bool have = polr_pool_next_unit(pp, u, c.lane);
 	while (have) {
@@ -332,9 +339,15 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 	}
 }
 
+#endif // !POLR_EXT
 // ---- launch ------------------------------------------------------------------------------------
 #define PASTE2(a, b) a##b
 #define PASTE(a, b) PASTE2(a, b)
+#if POLR_EXT
+#define POOLFN(stem) PASTE(PASTE(stem, POLR_K), x)
+#else
+#define POOLFN(stem) PASTE(stem, POLR_K)
+#endif
 
 static size_t pool_wave_dwords(uint32_t W) { // per probe wave of the generic kernel, never less than a router needs
 	const size_t queues = POLR_K <= 1 ? 0 : (size_t)W * QCAP1 + (size_t)(POLR_K - 2) * W * QCAPN;
@@ -343,6 +356,7 @@ static size_t pool_wave_dwords(uint32_t W) { // per probe wave of the generic ke
 	return probe > POOL_ROUTER_MIN_DWORDS ? probe : POOL_ROUTER_MIN_DWORDS;
 }
 
+#if !POLR_EXT
 static size_t pool_flat_wave_dwords() {
 	return (size_t)flat_per_wave_dwords<POLR_K>();
 }
@@ -354,12 +368,13 @@ static size_t pool_flat_lds_dwords(uint32_t waves_per_block, uint32_t table_dwor
 	const size_t router = (size_t)POOL_ROUTER_MIN_DWORDS * waves_per_block;
 	return probe > router ? probe : router;
 }
+#endif
 
 template <int W>
 static hipError_t pool_prepare(size_t lds) {
 	static size_t lds_set = 0;
 	if (lds > lds_set) {
-		hipError_t e = hipFuncSetAttribute((const void *)polr_pool_kernel<W, POLR_K>,
+		hipError_t e = hipFuncSetAttribute((const void *)polr_pool_kernel<W, POLR_K, POLR_EXT>,
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) {
 			return e;
@@ -369,6 +384,7 @@ static hipError_t pool_prepare(size_t lds) {
 	return hipSuccess;
 }
 
+#if !POLR_EXT
 static hipError_t pool_flat_prepare(size_t lds) {
 	static size_t lds_set = 0;
 	if (lds > lds_set) {
@@ -381,12 +397,13 @@ static hipError_t pool_flat_prepare(size_t lds) {
 	}
 	return hipSuccess;
 }
+#endif
 
 template <int W>
 static int pool_occupancy_w(size_t lds, uint32_t threads) {
 	int blocks = 0;
 	if (pool_prepare<W>(lds) != hipSuccess ||
-	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_pool_kernel<W, POLR_K>, (int)threads,
+	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_pool_kernel<W, POLR_K, POLR_EXT>, (int)threads,
 	                                                 lds) != hipSuccess) {
 		return 0;
 	}
@@ -402,7 +419,7 @@ static hipError_t pool_launch_w(dim3 grid, dim3 block, size_t lds, hipStream_t s
 	}
 	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&out, (void *)&lds_per_wave};
 	// (hipLaunchKernel returns the status of THIS launch: nothing is read from the thread's last-error slot)
-	return hipLaunchKernel((const void *)polr_pool_kernel<W, POLR_K>, grid, block, args, lds, stream);
+	return hipLaunchKernel((const void *)polr_pool_kernel<W, POLR_K, POLR_EXT>, grid, block, args, lds, stream);
 }
 
 template <int N>
@@ -411,11 +428,11 @@ struct PoolWc {
 };
 #define POLR_FOR_EACH_W(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
 
-extern "C++" size_t PASTE(polr_pool_lds_bytes_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
+extern "C++" size_t POOLFN(polr_pool_lds_bytes_k)(uint32_t W, uint32_t waves_per_block) {
 	return pool_wave_dwords(W) * waves_per_block * sizeof(uint32_t);
 }
 
-extern "C++" int PASTE(polr_pool_occupancy_k, POLR_K)(uint32_t W, uint32_t waves_per_block) {
+extern "C++" int POOLFN(polr_pool_occupancy_k)(uint32_t W, uint32_t waves_per_block) {
 	const size_t lds = pool_wave_dwords(W) * waves_per_block * sizeof(uint32_t);
 	if (W < 1 || W > POLR_K + 1) {
 		return 0;
@@ -429,7 +446,7 @@ extern "C++" int PASTE(polr_pool_occupancy_k, POLR_K)(uint32_t W, uint32_t waves
 	return 0;
 }
 
-extern "C++" hipError_t PASTE(polr_launch_pool_kernel_k, POLR_K)(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,
+extern "C++" hipError_t POOLFN(polr_launch_pool_kernel_k)(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,
                                                                  hipStream_t stream, const DevPipeline *pipe,
                                                                  const ResidentExec *execs, PoolRun *run, DevOut out) {
 	const uint32_t per_wave = (uint32_t)pool_wave_dwords(W);
@@ -447,6 +464,7 @@ extern "C++" hipError_t PASTE(polr_launch_pool_kernel_k, POLR_K)(uint32_t W, uin
 	return hipErrorInvalidValue;
 }
 
+#if !POLR_EXT
 extern "C++" size_t PASTE(polr_pool_flat_lds_bytes_k, POLR_K)(uint32_t waves_per_block, uint32_t table_dwords) {
 	return pool_flat_lds_dwords(waves_per_block, table_dwords) * sizeof(uint32_t);
 }
@@ -483,3 +501,4 @@ extern "C++" hipError_t PASTE(polr_launch_pool_flat_kernel_k, POLR_K)(uint32_t n
 	                (void *)&router_dwords};
 	return hipLaunchKernel((const void *)polr_pool_flat_kernel<POLR_K>, grid, block, args, lds, stream);
 }
+#endif // !POLR_EXT

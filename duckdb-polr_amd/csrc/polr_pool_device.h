@@ -103,7 +103,7 @@ struct PoolRun {
 	uint32_t hi_lottery;                    // power of two <= the probe waves of a ring: wave w of a ring tries for hi ticket t
 	                                        // only if w % hi_lottery == t % hi_lottery (bounds the compare-and-swap storm
 	                                        // a published unit sets off among the pollers of its ring)
-	uint32_t pad;
+	uint32_t idle_sleep;                    // longest s_sleep argument of an idle probe wave's back-off (16 .. 127)
 	uint32_t n_rings;                       // rings in use: a power of two <= min(POLR_POOL_RINGS, probe workgroups), so that
 	                                        // every ring has waves that serve it
 	uint32_t routers_done;                  // device: routers that have finished
@@ -140,22 +140,25 @@ struct PoolRoundOut {
 // unit size of a round: small rounds are spread 64 tuples per wave (the dependent-load chain of a step is the same
 // for 64 and for 512 tuples: more waves in parallel is strictly faster); big rounds are cut so that one executor's
 // round gives every probe wave of its share of the pool a few units, in multiples of `gran` tuples
-__device__ __forceinline__ void polr_pool_size_units(uint64_t tuples, uint32_t pool_waves, uint32_t n_exec, uint32_t gran,
+__device__ __forceinline__ void polr_pool_size_units(uint64_t tuples64, uint32_t pool_waves, uint32_t n_exec, uint32_t gran,
                                                      uint32_t hi_tuples, uint32_t units_x, uint32_t hi_unit, bool terminal,
                                                      PoolRoundOut &r) {
+	// (32-bit arithmetic: a round is at most 2^32 - 1 tuples, and the device has no integer divider -- a 64-bit
+	// division is a ~150-instruction sequence on the router's single lane; gran is a power of two)
+	const uint32_t tuples = (uint32_t)tuples64;
 	if (tuples <= hi_tuples) {
 		r.cls = 0;
 		r.unit = hi_unit;
 	} else {
 		r.cls = terminal ? 2u : 1u;
-		uint64_t target = (uint64_t)units_x * pool_waves / (n_exec ? n_exec : 1u);
-		target = target < 16 ? 16 : target;
-		uint64_t us = (tuples + target - 1) / target;
-		us = ((us + gran - 1) / gran) * gran;
+		uint32_t target = units_x * pool_waves / (n_exec ? n_exec : 1u);
+		target = target < 16u ? 16u : target;
+		uint32_t us = tuples / target + (tuples % target ? 1u : 0u);
+		us = (us + gran - 1u) & ~(gran - 1u);
 		// (never more than 65 536 tuples: the flat pipeline queues 16-bit positions inside the unit)
-		r.unit = (uint32_t)(us < gran ? gran : (us > 65536ull ? 65536ull : us));
+		r.unit = us < gran ? gran : (us > 65536u ? 65536u : us);
 	}
-	r.n_units = (uint32_t)((tuples + r.unit - 1) / r.unit);
+	r.n_units = tuples / r.unit + (tuples % r.unit ? 1u : 0u);
 }
 
 // sum of the 8 arrival shards of a slot (full wave; the same value in every lane)
@@ -313,13 +316,13 @@ struct PoolPoller {
 	POLR_GLOBAL PoolRun *run;
 	POLR_GLOBAL PoolRingCtl *ctl;
 	POLR_GLOBAL PoolEntry *hi_q, *mid_q, *lo_q;
-	uint32_t lo_cap, hi_cap, wave_in_ring, lottery;
+	uint32_t lo_cap, hi_cap, wave_in_ring, lottery, idle_sleep;
 	unsigned long long lo_ticket, mid_ticket; // ~0ull: none
 };
 
 __device__ __forceinline__ void polr_pool_poller_init(PoolPoller &pp, PoolRun *run_generic, PoolSync *sync_generic,
                                                       uint32_t ring, uint32_t lo_cap, uint32_t hi_cap,
-                                                      uint32_t wave_in_ring, uint32_t lottery) {
+                                                      uint32_t wave_in_ring, uint32_t lottery, uint32_t idle_sleep) {
 	pp.run = as_global(run_generic);
 	pp.ctl = as_global(&sync_generic->ctl[ring]);
 	pp.hi_q = as_global(polr_pool_hi(sync_generic, ring, lo_cap, hi_cap));
@@ -329,6 +332,7 @@ __device__ __forceinline__ void polr_pool_poller_init(PoolPoller &pp, PoolRun *r
 	pp.hi_cap = hi_cap;
 	pp.wave_in_ring = wave_in_ring;
 	pp.lottery = lottery;
+	pp.idle_sleep = idle_sleep;
 	pp.lo_ticket = pp.mid_ticket = ~0ull;
 }
 
@@ -405,7 +409,7 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolPoller &pp, PoolUnit &u,
 		spins++;
 		if (spins < 8) {
 			__builtin_amdgcn_s_sleep(2);
-		} else if (spins < 32) {
+		} else if (spins < 32 || pp.idle_sleep < 64) {
 			__builtin_amdgcn_s_sleep(16);
 		} else {
 			__builtin_amdgcn_s_sleep(64);
@@ -481,9 +485,17 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		for (uint32_t i = lane; i < POLR_MAX_PATHS * POLR_MAX_JOINS; i += 64) {
 			mg->stage_out[i / POLR_MAX_JOINS][i % POLR_MAX_JOINS] = 0;
 		}
+		{
+			static_assert(sizeof(polr::MultiplexerCore) % 4 == 0, "cleared in dwords");
+			uint32_t *cw = (uint32_t *)&m->core;
+			for (uint32_t i = lane; i < sizeof(polr::MultiplexerCore) / 4; i += 64) {
+				cw[i] = 0;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
 		if (lane == 0) {
 			const polr_mpx_config cfg = m->cfg;
-			m->core.Init(cfg.routing, m->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
+			m->core.InitAfterZero(cfg.routing, m->n_paths, cfg.regret_budget, cfg.init_tuple_count, cfg.atc_multiplier);
 			m->num_intermediates_total = 0;
 			m->num_rounds = 0;
 			m->n_log = 0;
@@ -537,8 +549,10 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	uint32_t rot = exec; // units of consecutive rounds start on different rings
 	// one routing step on whatever state sits in `lds` (the real one, or the shadow swapped in): the round it decides
 	auto route_here = [&](PoolRoundOut &r) -> bool {
+		// (asked for before the routing code runs, used after it: a sizing hint, one global round trip off the path)
+		const uint32_t done_now = __hip_atomic_load(&run->routers_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (lane == 0) {
-			polr_router_route(m, round, prefix, us, rh.pool_waves, &oc);
+			polr_router_route(m, round, prefix, us, rh.pool_waves, &oc, false);
 			if (x.path_plus1) {
 				// BACKPRESSURE (src/parallel/pipeline.cpp:147-156, polar_config.cpp:128-147): this executor IS one
 				// join order; its multiplexer routes DEFAULT_PATH, the order it stands for replaces path 0
@@ -554,13 +568,9 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 		r.path = vr->path;
 		r.emit = vr->emit;
 		// a round is cut for the executors that are still routing: the last ones get the whole pool
-		uint32_t active = rh.n_exec;
-		if (r.count > rh.hi_tuples) {
-			// (routers_done counts executors that have finished ROUTING; their terminal rounds may still
-			// be queued, which is what the lo queue is for)
-			const uint32_t done_now = __hip_atomic_load(&run->routers_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			active = done_now < rh.n_exec ? rh.n_exec - done_now : 1u;
-		}
+		// (routers_done counts executors that have finished ROUTING; their terminal rounds may still be queued, which
+		// is what the lo queue is for)
+		const uint32_t active = done_now < rh.n_exec ? rh.n_exec - done_now : 1u;
 		const bool terminal = ((volatile DevMpx *)m)->core.num_cache_flushing_skips == polr::kIdxMax;
 		polr_pool_size_units(r.count, rh.pool_waves, active, gran, rh.hi_tuples, rh.units_x, rh.hi_unit, terminal, r);
 		return done;

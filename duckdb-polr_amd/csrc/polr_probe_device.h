@@ -3,6 +3,13 @@
 // See polr_probe.hip for the execution model.  Needs POLR_K (compiled stage count) defined by the including file.
 #pragma once
 
+// POLR_EXT = 1 builds the generic pipeline with its uncommon parts (composite keys in packed form, non-equality join
+// conditions); pipelines that need neither run on the POLR_EXT = 0 build of the same kernels, whose stages carry no trace
+// of them (inlined into every place a stage fetches keys or emits matches they doubled the scalar-register spills)
+#ifndef POLR_EXT
+#define POLR_EXT 1
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -94,8 +101,9 @@ struct Tuple {
 
 // per-stage descriptor pulled from LDS into wave-uniform registers
 struct Stage {
-	uint32_t kind, n_keys, key_width0, key_width1, key_signed, packed, n_preds;
-	const StageDesc *desc; // the descriptor in LDS (packed composite keys read theirs from there)
+	uint32_t kind, n_keys, key_width0, key_width1, key_signed;
+	uint32_t xflags; // POLR_EXT builds: bit 0 = composite key in packed form, bits 8.. = number of non-equality
+	                 // conditions (both rare: their descriptors are read from the stage's extension record at use)
 	int32_t key_slot0, key_slot1, out_slot;
 	const uint8_t *key_data0, *key_valid0, *key_data1, *key_valid1;
 	const void *table;
@@ -110,9 +118,11 @@ __device__ __forceinline__ Stage load_stage(const StageDesc *d) {
 	Stage s;
 	s.kind = uni(d->kind);
 	s.n_keys = uni(d->n_keys);
-	s.packed = uni(d->pack.packed);
-	s.n_preds = uni(d->n_preds);
-	s.desc = d;
+#if POLR_EXT
+	s.xflags = uni(d->packed | (d->n_preds << 8));
+#else
+	s.xflags = 0; // (pipelines with packed keys or conditions are launched on the POLR_EXT build of these kernels)
+#endif
 	s.key_width0 = uni(d->key_width[0]);
 	s.key_width1 = uni(d->key_width[1]);
 	s.key_signed = uni(d->key_signed);
@@ -146,16 +156,17 @@ __device__ __forceinline__ uint32_t tuple_slot(const Tuple<W> &t, int32_t slot) 
 // key of this lane's tuple; false for NULL (NULL never matches: join_hashtable.cpp:170-192,
 // perfect_hash_join_executor.cpp:272-277)
 template <int W>
-__device__ __forceinline__ bool fetch_key(const Stage &s, const Tuple<W> &t, bool active, uint64_t &key) {
+__device__ __forceinline__ bool fetch_key(const Stage &s, const StageDesc *desc, const Tuple<W> &t, bool active,
+                                          uint64_t &key) {
 	key = 0;
 	if (!active) {
 		return false;
 	}
-	if (s.packed) {
+#if POLR_EXT
+	if (s.xflags & 1u) {
 		// composite key in packed form (KeyPack): per column (value - min) << shift; a value outside the build side's
-		// [min, min + range] cannot match.  Everything comes from the LDS descriptor: the uncommon case pays a few LDS
-		// reads instead of every pipeline carrying four key columns in scalar registers.
-		const StageDesc *d = s.desc;
+		// [min, min + range] cannot match.  Everything comes from the extension record in global memory.
+		const StageExt *d = uniptr(desc->ext);
 		bool valid = true;
 		for (uint32_t c = 0; c < s.n_keys; c++) {
 			const uint32_t row = tuple_slot<W>(t, d->key_slot[c]);
@@ -176,6 +187,7 @@ __device__ __forceinline__ bool fetch_key(const Stage &s, const Tuple<W> &t, boo
 		}
 		return valid;
 	}
+#endif
 	const bool sx = s.kind == KIND_PERFECT && s.key_signed != 0;
 	const uint32_t row0 = tuple_slot<W>(t, s.key_slot0);
 	bool valid = !(s.key_valid0 && !s.key_valid0[row0]);
@@ -400,12 +412,13 @@ __device__ __forceinline__ void out_write(WaveCtx<W, K> &c, const Tuple<W> &t, b
 }
 
 // the join's non-equality conditions on one (tuple, build row) pair (RowOperations::Match, row_match.cpp:59-119:
-// both sides valid and `left OP right`); descriptors come from LDS -- joins that have any are rare
+// both sides valid and `left OP right`); descriptors come from the extension record -- joins that have any are rare
 template <int W>
-__device__ __forceinline__ bool preds_hold(const Stage &s, const Tuple<W> &t, uint32_t id) {
-	const StageDesc *d = s.desc;
+__device__ __forceinline__ bool preds_hold(const Stage &s, const StageDesc *desc, const Tuple<W> &t, uint32_t id) {
+	const StageExt *d = uniptr(desc->ext);
+	const uint32_t n_preds = s.xflags >> 8;
 	bool ok = true;
-	for (uint32_t c = 0; c < s.n_preds; c++) {
+	for (uint32_t c = 0; c < n_preds; c++) {
 		const uint32_t row = tuple_slot<W>(t, d->pred_slot[c]);
 		const uint32_t w = d->pred_width[c];
 		const bool sx = d->pred_sx[c] != 0;
@@ -442,10 +455,12 @@ __device__ __forceinline__ bool preds_hold(const Stage &s, const Tuple<W> &t, ui
 // push the matches of stage POS to the next stage (or to the output when POS is the last join)
 template <int W, int K, int POS>
 __device__ __forceinline__ void emit_tuples(WaveCtx<W, K> &c, const Stage &s, Tuple<W> t, uint32_t id, bool valid) {
-	if (s.n_preds) {
+#if POLR_EXT
+	if (s.xflags >> 8) {
 		// (inactive lanes carry arbitrary ids: evaluate on the matches only)
-		valid = valid && preds_hold<W>(s, t, id);
+		valid = valid && preds_hold<W>(s, &c.desc[POS], t, id);
 	}
+#endif
 #pragma unroll
 	for (int i = 1; i < W; i++) {
 		t.s[i] = (i == s.out_slot) ? id : t.s[i];
@@ -522,7 +537,7 @@ __device__ __forceinline__ void resume_expansion(WaveCtx<W, K> &c) {
 		}
 	}
 	uint32_t id = 0;
-	if (valid && (s.out_slot >= 0 || s.n_preds)) { // (the build id is needed: carried on, or read by a condition)
+	if (valid && (s.out_slot >= 0 || (s.xflags >> 8))) { // (the build id is needed: carried on, or read by a condition)
 		id = s.rowids[st + r];
 	}
 	emit_tuples<W, K, POS>(c, s, t, id, valid);
@@ -571,7 +586,7 @@ __device__ __forceinline__ void run_stage(WaveCtx<W, K> &c) {
 		c.qsize[POS] = base;
 	}
 	uint64_t key;
-	const bool valid = fetch_key<W>(s, t, active, key);
+	const bool valid = fetch_key<W>(s, &c.desc[POS], t, active, key);
 	if (s.kind == KIND_PERFECT) {
 		uint32_t id;
 		const bool hit = lookup_perfect(s, key, valid, id);
@@ -586,7 +601,7 @@ __device__ __forceinline__ void run_stage(WaveCtx<W, K> &c) {
 		const bool multi = __ballot(count > 1) != 0ull;
 		if (!multi) {
 			uint32_t id = 0;
-			if (count && (s.out_slot >= 0 || s.n_preds)) {
+			if (count && (s.out_slot >= 0 || (s.xflags >> 8))) {
 				id = s.rowids[start];
 			}
 			emit_tuples<W, K, POS>(c, s, t, id, count != 0);
@@ -659,7 +674,7 @@ __device__ __forceinline__ void run_stage_wide(WaveCtx<W, K> &c) {
 	bool valid[WIDE];
 #pragma unroll
 	for (int i = 0; i < WIDE; i++) {
-		valid[i] = fetch_key<W>(s, t[i], act[i], key[i]);
+		valid[i] = fetch_key<W>(s, &c.desc[POS], t[i], act[i], key[i]);
 	}
 	uint32_t id[WIDE];
 	bool hit[WIDE];
@@ -741,7 +756,7 @@ __device__ __forceinline__ void run_stage_wide(WaveCtx<W, K> &c) {
 			start[i] = p[i].start;
 			cnt[i] = p[i].count;
 			multi[i] = __ballot(p[i].count > 1) != 0ull;
-			id[i] = (hit[i] && (s.out_slot >= 0 || s.n_preds)) ? s.rowids[p[i].start] : 0u;
+			id[i] = (hit[i] && (s.out_slot >= 0 || (s.xflags >> 8))) ? s.rowids[p[i].start] : 0u;
 		}
 	}
 	bool any_multi = false;
@@ -822,7 +837,7 @@ __device__ __forceinline__ void resume_expansion_wide(WaveCtx<W, K> &c) {
 	uint32_t id[WIDE];
 #pragma unroll
 	for (int j = 0; j < WIDE; j++) {
-		id[j] = (valid[j] && (s.out_slot >= 0 || s.n_preds)) ? s.rowids[pos[j]] : 0u;
+		id[j] = (valid[j] && (s.out_slot >= 0 || (s.xflags >> 8))) ? s.rowids[pos[j]] : 0u;
 	}
 #pragma unroll
 	for (int j = 0; j < WIDE; j++) {

@@ -115,6 +115,21 @@ struct MultiplexerCore {
 		eb_min_resistance = 1.7976931348623157e308;
 	}
 
+	// Init() for an object whose bytes are all zero already (a device router clears the struct with the whole wave:
+	// Init's field-by-field zeroing is some 230 dependent LDS stores on its single routing lane)
+	POLR_HD void InitAfterZero(uint32_t routing_p, uint32_t path_count_p, double regret_budget_p,
+	                           uint64_t init_tuple_count_p, uint64_t multiplier_p) {
+		routing = routing_p;
+		path_count = path_count_p;
+		regret_budget = regret_budget_p;
+		init_tuple_count = init_tuple_count_p;
+		multiplier = multiplier_p;
+		first_mpx_run = 1;
+		max_window_size = routing_p == EXPONENTIAL_BACKOFF ? (uint64_t)regret_budget_p : 0;
+		eb_min_path = kIdxMax;
+		eb_min_resistance = 1.7976931348623157e308;
+	}
+
 	// ---- reward -------------------------------------------------------------------------------
 	POLR_HD void AddNumIntermediates(uint64_t n) {
 		num_intermediates_current_path += n; // physical_multiplexer.cpp:181-184
