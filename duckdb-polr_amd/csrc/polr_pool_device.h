@@ -44,14 +44,22 @@
 // [0] waiting for the front round, [1] absorbing its counters, [2] the real routing step, [3] publishing,
 // [4] rehearsals (route + publish), [5] steps, [6] entry .. first publish, [7] routers,
 // [8] entry .. state in LDS, [9] .. state initialised, [10] .. arrival targets known (= first step begins)
+// (summed in registers, one set of atomics per router when it leaves: per-step atomics on eleven words slowed every
+// atomic of the run down)
 #define RT_T(v_) const unsigned long long v_ = wall_clock64();
-#define RT_ADD(i_, d_)                                                                                                 \
+#define RT_DECL unsigned long long rt_acc[11] = {};
+#define RT_ADD(i_, d_) rt_acc[i_] += (unsigned long long)(d_);
+#define RT_FLUSH                                                                                                       \
 	if (lane == 0) {                                                                                                   \
-		atomicAdd(&polr_diag_router[i_], (unsigned long long)(d_));                                                    \
+		_Pragma("unroll") for (int i_ = 0; i_ < 11; i_++) {                                                            \
+			atomicAdd(&polr_diag_router[i_], rt_acc[i_]);                                                              \
+		}                                                                                                              \
 	}
 #else
 #define RT_T(v_)
+#define RT_DECL
 #define RT_ADD(i_, d_)
+#define RT_FLUSH
 #endif
 
 #define POLR_POOL_RINGS 64 // unit queues; counters and arrivals are sharded 8 ways (ring & 7)
@@ -434,6 +442,7 @@ __device__ __forceinline__ bool polr_pool_next_unit(PoolPoller &pp, PoolUnit &u,
 __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun *run, const PoolRun &rh, uint32_t exec,
                                                  uint32_t k, uint32_t gran, uint32_t lane, uint32_t *lds,
                                                  uint64_t *cache_lds, uint32_t cache_cap, uint32_t *scratch_lds) {
+	RT_DECL
 	RT_T(rt_entry)
 	DevMpx *mg = x.mpx;
 	PoolSync *sync = rh.sync;
@@ -765,6 +774,7 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			dst[i] = lds[i];
 		}
 	}
+	RT_FLUSH
 	// the router that finishes last lets the pool go
 	uint32_t last = 0;
 	if (lane == 0) {
