@@ -271,18 +271,33 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         # the path's one exchange step, in the product: polr_bcast_build (librccl, ncclBroadcast over xGMI) -- rank 0's
         # finalized tables to every rank.  torch.distributed only carries the 128-byte communicator id.
         # (POLR_DIST_BACKEND=gloo rehearsals on one GPU cannot form an RCCL communicator: they build locally)
-        if env.get("comm") is None and os.environ.get("POLR_DIST_BACKEND", "nccl") == "nccl":
-            idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if env.get("comm") is None and not env.get("comm_failed") and not os.environ.get("POLR_SHARE_DEVICE"):
+            # (POLR_SHARE_DEVICE rehearsals put several ranks on one GPU, which RCCL refuses: they build locally)
+            idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 idt.copy_(torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
-            env["comm"] = capi.Comm(ctx, bytes(idt.cpu().numpy().tobytes()), world, rank)
+            ok = torch.ones(1, dtype=torch.int32)
+            try:
+                env["comm"] = capi.Comm(ctx, bytes(idt.numpy().tobytes()), world, rank)
+            except capi.PolrError as e:
+                # the measurement goes on with locally built tables (same bytes: the build is deterministic); the line
+                # says so -- the probe path itself is unaffected
+                env["comm_failed"] = str(e)
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0 and env.get("comm") is not None:
+                env["comm"].close()
+                env["comm"] = None
+                env["comm_failed"] = env.get("comm_failed") or "communicator creation failed on another rank"
         comm = env.get("comm")
         if comm is not None:
             before = comm.bytes_broadcast()
             got = []
             for x in range(k):
                 ht = comm.bcast_build(joins[x][0] if rank == 0 else None, root=0)
+                pnames = list(wl0["joins"][x]["payload"].keys())
+                ht.preds = [(op, src, pnames.index(col)) for op, src, col in wl0["joins"][x].get("preds", [])]
                 got.append((ht, wl0["joins"][x]["key_src"]))
             joins = got
             bcast_bytes = comm.bytes_broadcast() - before
@@ -574,6 +589,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],
             "generate_s": round(t_gen, 3), "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
+            "build_broadcast": ("polr_bcast_build over RCCL" if bcast_bytes else (("built on every rank: " + str(env.get("comm_failed") or "ranks share one device")) if world > 1 else "single rank")),
             "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch_info": info,
             "artefacts": artefacts,
             "timed_region": {"gpu": "routing + probing of every source chunk; probe key columns read from HBM inside the "
@@ -863,7 +879,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("POLR_DIST_BACKEND", "nccl")
+        # control plane (rendezvous, the 128-byte communicator id, barriers, the max-over-ranks reduction): gloo.  The
+        # data-path exchange -- the build sides -- goes over RCCL inside the library (polr_bcast_build, its own
+        # communicator); torch's own RCCL (a second copy, on torch's bundled HIP runtime) is left out of the process
+        # unless POLR_DIST_BACKEND=nccl asks for it
+        backend = os.environ.get("POLR_DIST_BACKEND", "gloo")
         if os.environ.get("POLR_SHARE_DEVICE"):
             local_rank = 0
         if backend == "nccl":

@@ -43,8 +43,11 @@ struct Rccl {
 Rccl &rccl() {
 	static Rccl r = [] {
 		Rccl x;
-		for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		// The ROCm installation's RCCL first, by path and RTLD_LOCAL: a host process may already carry ANOTHER copy of RCCL
+		// (PyTorch bundles one, linked against its own bundled HIP runtime) -- a dlopen by soname would hand that copy
+		// back, and the streams of this library belong to the HIP runtime THIS library links
+		for (const char *name : {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"}) {
+			x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
 			if (x.lib) {
 				break;
 			}
