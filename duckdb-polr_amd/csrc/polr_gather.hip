@@ -123,16 +123,20 @@ DECL_K(4)
 DECL_K(6)
 DECL_K(8)
 struct PoolRun;
+// (POLR_EXT builds of the generic pool kernel: 4 and 8 compiled stages only)
+#define DECL_POOL_X(KK)                                                                                                \
+	int polr_pool_occupancy_k##KK##x(uint32_t W, uint32_t waves_per_block);                                           \
+	hipError_t polr_launch_pool_kernel_k##KK##x(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,              \
+	                                            hipStream_t stream, const DevPipeline *pipe,                         \
+	                                            const ResidentExec *execs, PoolRun *run, DevOut out);
+DECL_POOL_X(4)
+DECL_POOL_X(8)
 #define DECL_POOL_K(KK)                                                                                                \
 	size_t polr_pool_lds_bytes_k##KK(uint32_t W, uint32_t waves_per_block);                                           \
 	int polr_pool_occupancy_k##KK(uint32_t W, uint32_t waves_per_block);                                              \
 	hipError_t polr_launch_pool_kernel_k##KK(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,                 \
 	                                         hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs, \
 	                                         PoolRun *run, DevOut out);                                              \
-	int polr_pool_occupancy_k##KK##x(uint32_t W, uint32_t waves_per_block);                                           \
-	hipError_t polr_launch_pool_kernel_k##KK##x(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,              \
-	                                            hipStream_t stream, const DevPipeline *pipe,                         \
-	                                            const ResidentExec *execs, PoolRun *run, DevOut out);                \
 	size_t polr_pool_flat_lds_bytes_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                           \
 	size_t polr_pool_flat_wave_bytes_k##KK();                                                                         \
 	int polr_pool_flat_occupancy_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                              \
@@ -215,8 +219,7 @@ extern "C++" size_t polr_pool_lds_bytes(uint32_t k, uint32_t W, uint32_t wpb) {
 // ext: the pipeline has stages with an extension record (DevPipeline::ext) -> the POLR_EXT build of the generic kernel
 extern "C++" int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t wpb, bool ext) {
 	if (ext) {
-		POOL_SWITCH(k, polr_pool_occupancy_k2x(W, wpb), polr_pool_occupancy_k4x(W, wpb), polr_pool_occupancy_k6x(W, wpb),
-		            polr_pool_occupancy_k8x(W, wpb))
+		return k <= 4 ? polr_pool_occupancy_k4x(W, wpb) : polr_pool_occupancy_k8x(W, wpb);
 	}
 	POOL_SWITCH(k, polr_pool_occupancy_k2(W, wpb), polr_pool_occupancy_k4(W, wpb), polr_pool_occupancy_k6(W, wpb),
 	            polr_pool_occupancy_k8(W, wpb))
@@ -226,10 +229,8 @@ extern "C++" hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t
                                                 const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run,
                                                 DevOut out, bool ext) {
 	if (ext) {
-		POOL_SWITCH(k, polr_launch_pool_kernel_k2x(W, n_blocks, wpb, stream, pipe, execs, run, out),
-		            polr_launch_pool_kernel_k4x(W, n_blocks, wpb, stream, pipe, execs, run, out),
-		            polr_launch_pool_kernel_k6x(W, n_blocks, wpb, stream, pipe, execs, run, out),
-		            polr_launch_pool_kernel_k8x(W, n_blocks, wpb, stream, pipe, execs, run, out))
+		return k <= 4 ? polr_launch_pool_kernel_k4x(W, n_blocks, wpb, stream, pipe, execs, run, out)
+		              : polr_launch_pool_kernel_k8x(W, n_blocks, wpb, stream, pipe, execs, run, out);
 	}
 	POOL_SWITCH(k, polr_launch_pool_kernel_k2(W, n_blocks, wpb, stream, pipe, execs, run, out),
 	            polr_launch_pool_kernel_k4(W, n_blocks, wpb, stream, pipe, execs, run, out),
