@@ -153,6 +153,37 @@ __device__ __forceinline__ uint32_t tuple_slot(const Tuple<W> &t, int32_t slot) 
 	return v;
 }
 
+#if POLR_EXT
+// composite key in packed form (KeyPack): per column (value - min) << shift; a value outside the build side's
+// [min, min + range] cannot match.  Everything comes from the extension record in global memory.  A function of its own
+// (like preds_hold below): inlined into every place a stage fetches keys, the uncommon paths made the POLR_EXT objects
+// the slowest of the build by minutes -- the pipelines that take them can afford a call.
+template <int W>
+__device__ __attribute__((noinline)) bool fetch_key_packed(const StageExt *d, uint32_t n_keys, const Tuple<W> &t,
+                                                           uint64_t &key) {
+	bool valid = true;
+	key = 0;
+	for (uint32_t c = 0; c < n_keys; c++) {
+		const uint32_t row = tuple_slot<W>(t, d->key_slot[c]);
+		const uint8_t *kv = d->key_valid[c];
+		if (kv && !kv[row]) {
+			valid = false;
+		}
+		const uint32_t w = d->key_width[c];
+		const uint64_t v = load_cell(d->key_data[c] + (uint64_t)row * w, w, d->pack.sx[c] != 0);
+		const uint64_t off = v - (uint64_t)d->pack.min[c];
+		if (off > d->pack.range[c]) {
+			valid = false;
+		}
+		key |= off << d->pack.shift[c];
+	}
+	if (!valid) {
+		key = 0;
+	}
+	return valid;
+}
+#endif
+
 // key of this lane's tuple; false for NULL (NULL never matches: join_hashtable.cpp:170-192,
 // perfect_hash_join_executor.cpp:272-277)
 template <int W>
@@ -164,28 +195,7 @@ __device__ __forceinline__ bool fetch_key(const Stage &s, const StageDesc *desc,
 	}
 #if POLR_EXT
 	if (s.xflags & 1u) {
-		// composite key in packed form (KeyPack): per column (value - min) << shift; a value outside the build side's
-		// [min, min + range] cannot match.  Everything comes from the extension record in global memory.
-		const StageExt *d = uniptr(desc->ext);
-		bool valid = true;
-		for (uint32_t c = 0; c < s.n_keys; c++) {
-			const uint32_t row = tuple_slot<W>(t, d->key_slot[c]);
-			const uint8_t *kv = d->key_valid[c];
-			if (kv && !kv[row]) {
-				valid = false;
-			}
-			const uint32_t w = d->key_width[c];
-			const uint64_t v = load_cell(d->key_data[c] + (uint64_t)row * w, w, d->pack.sx[c] != 0);
-			const uint64_t off = v - (uint64_t)d->pack.min[c];
-			if (off > d->pack.range[c]) {
-				valid = false;
-			}
-			key |= off << d->pack.shift[c];
-		}
-		if (!valid) {
-			key = 0;
-		}
-		return valid;
+		return fetch_key_packed<W>(uniptr(desc->ext), s.n_keys, t, key);
 	}
 #endif
 	const bool sx = s.kind == KIND_PERFECT && s.key_signed != 0;
@@ -414,9 +424,7 @@ __device__ __forceinline__ void out_write(WaveCtx<W, K> &c, const Tuple<W> &t, b
 // the join's non-equality conditions on one (tuple, build row) pair (RowOperations::Match, row_match.cpp:59-119:
 // both sides valid and `left OP right`); descriptors come from the extension record -- joins that have any are rare
 template <int W>
-__device__ __forceinline__ bool preds_hold(const Stage &s, const StageDesc *desc, const Tuple<W> &t, uint32_t id) {
-	const StageExt *d = uniptr(desc->ext);
-	const uint32_t n_preds = s.xflags >> 8;
+__device__ __attribute__((noinline)) bool preds_hold(const StageExt *d, uint32_t n_preds, const Tuple<W> &t, uint32_t id) {
 	bool ok = true;
 	for (uint32_t c = 0; c < n_preds; c++) {
 		const uint32_t row = tuple_slot<W>(t, d->pred_slot[c]);
@@ -458,7 +466,7 @@ __device__ __forceinline__ void emit_tuples(WaveCtx<W, K> &c, const Stage &s, Tu
 #if POLR_EXT
 	if (s.xflags >> 8) {
 		// (inactive lanes carry arbitrary ids: evaluate on the matches only)
-		valid = valid && preds_hold<W>(s, &c.desc[POS], t, id);
+		valid = valid && preds_hold<W>(uniptr(c.desc[POS].ext), s.xflags >> 8, t, id);
 	}
 #endif
 #pragma unroll
