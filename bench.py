@@ -330,6 +330,9 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             dt_s = time.perf_counter() - t_s
             best = dt_s if best is None else min(best, dt_s)
         scan_bytes = 2 * sum(tens[names.index(c)].element_size() for c, _, _ in (flt or [])) * n_rows + 4 * n_tuples
+        # LIP: the probe key column of every pre-filtered join is read once per pass of the scan (count + write)
+        scan_bytes += 2 * n_rows * sum(tens[j["key_src"][0][1]].element_size() for x, j in enumerate(wl0["joins"])
+                                       if (lip_mask >> x) & 1)
         scan_info = {"rows": n_rows, "selected": int(n_tuples), "chunks": int(n_chunks),
                      "ms": round(best * 1e3, 4), "algorithmic_bytes": int(scan_bytes),
                      "GB/s": round(scan_bytes / best / 1e9, 1),
