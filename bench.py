@@ -375,6 +375,18 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         sets.append(execs)
     raw_results = [None]
     ranges = [(x[1], x[2]) for x in sets[0]]
+    # --ranges-per-executor R: executor e owns R ranges, one out of every R-th part of the source (part r: chunks
+    # [r n / R, (r + 1) n / R), cut E ways) -- every executor sees every stretch of a skewed table
+    range_lists = None
+    R = max(1, args.ranges_per_executor)
+    if R > 1 and not args.morsels:
+        range_lists = []
+        for e in range(E):
+            lst = []
+            for r in range(R):
+                lo_r, hi_r = (r * n_chunks) // R, ((r + 1) * n_chunks) // R
+                lst.append((lo_r + (e * (hi_r - lo_r)) // E, lo_r + ((e + 1) * (hi_r - lo_r)) // E))
+            range_lists.append(lst)
     all_mpxs = [x[0] for ex in sets for x in ex]
     step_no = [0]
     pipelined = not args.sync_every_step
@@ -386,7 +398,10 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         if args.morsels > 0:
             capi.run_resident_morsels(cur, 0, n_chunks, args.morsels, reset=True, finish=True, share=P)
         else:
-            capi.run_resident(cur, ranges, reset=True, finish=True, share=max(P, pool_share))
+            if range_lists is not None:
+                capi.run_resident_ranges(cur, range_lists, reset=True, finish=True, share=max(P, pool_share))
+            else:
+                capi.run_resident(cur, ranges, reset=True, finish=True, share=max(P, pool_share))
         if fetch:
             for ex in sets:  # (settles every stream; the statistics reported are the last pass's)
                 ms_ = [x[0] for x in ex]
@@ -853,6 +868,8 @@ def main():
                          "1 M-value cap); default: polr_ht_finalize_auto")
     ap.add_argument("--host-filter", action="store_true")
     ap.add_argument("--morsels", type=int, default=0)
+    ap.add_argument("--ranges-per-executor", type=int, default=1,
+                    help="every executor owns this many chunk ranges, one out of each part of the source (1..8)")
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--sync-every-step", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -522,9 +522,10 @@ static uint32_t next_pow2_u32(uint64_t v) {
 #define POOL_HEADER_BYTES 512
 static_assert(sizeof(PoolRun) <= POOL_HEADER_BYTES, "run header");
 
+// ranges_per_exec > 1: chunk_begin / chunk_end are [n][ranges_per_exec] (executor i routes its ranges in order)
 static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                              uint32_t n, polr_out *out, uint32_t flags, uint64_t morsel_begin, uint64_t morsel_end,
-                             uint32_t morsel_chunks, bool backpressure = false) {
+                             uint32_t morsel_chunks, bool backpressure = false, uint32_t ranges_per_exec = 1) {
 	if (!ms || n == 0 || !ms[0] || (morsel_chunks == 0 && (!chunk_begin || !chunk_end))) {
 		return POLR_E_INVALID;
 	}
@@ -547,11 +548,13 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		if (!ms[i]->chunk_offsets_owned && (!p->scan_valid || ms[i]->scan_generation != p->scan_generation)) {
 			POLR_FAIL(ctx, POLR_E_INVALID, "the pipeline was scanned again: call polr_mpx_use_scan_chunks");
 		}
-		const uint64_t cb = morsel_chunks ? morsel_begin : chunk_begin[i];
-		const uint64_t ce = morsel_chunks ? morsel_end : chunk_end[i];
-		if (cb > ce || ce > ms[i]->n_chunks) {
-			POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks", (unsigned long long)cb,
-			          (unsigned long long)ce, (unsigned long long)ms[i]->n_chunks);
+		for (uint32_t r = 0; r < (morsel_chunks ? 1u : ranges_per_exec); r++) {
+			const uint64_t cb = morsel_chunks ? morsel_begin : chunk_begin[(size_t)i * ranges_per_exec + r];
+			const uint64_t ce = morsel_chunks ? morsel_end : chunk_end[(size_t)i * ranges_per_exec + r];
+			if (cb > ce || ce > ms[i]->n_chunks) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "chunks [%llu, %llu) outside the %llu source chunks", (unsigned long long)cb,
+				          (unsigned long long)ce, (unsigned long long)ms[i]->n_chunks);
+			}
 		}
 	}
 	{
@@ -718,8 +721,13 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ex[i].mpx = m->dev;
 		ex[i].sync = m->sync_dev;
 		ex[i].counts = m->counts_dev;
-		ex[i].chunk_begin = morsel_chunks ? 0 : chunk_begin[i];
-		ex[i].chunk_end = morsel_chunks ? 0 : chunk_end[i];
+		ex[i].chunk_begin = morsel_chunks ? 0 : chunk_begin[(size_t)i * ranges_per_exec];
+		ex[i].chunk_end = morsel_chunks ? 0 : chunk_end[(size_t)i * ranges_per_exec];
+		ex[i].n_more = morsel_chunks ? 0 : ranges_per_exec - 1;
+		for (uint32_t r = 1; r < ranges_per_exec && !morsel_chunks; r++) {
+			ex[i].more_begin[r - 1] = chunk_begin[(size_t)i * ranges_per_exec + r];
+			ex[i].more_end[r - 1] = chunk_end[(size_t)i * ranges_per_exec + r];
+		}
 		ex[i].morsel_cursor = morsel_chunks ? cursor_dev : nullptr;
 		ex[i].morsel_end = morsel_end;
 		ex[i].morsel_chunks = morsel_chunks;
@@ -782,6 +790,15 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		ms[i]->pending_sync = true;
 	}
 	return POLR_OK;
+}
+
+int polr_mpx_run_resident_ranges(polr_mpx **ms, void *stream, const uint64_t *range_begin, const uint64_t *range_end,
+                                 uint32_t ranges_per_executor, uint32_t n, polr_out *out, uint32_t flags) {
+	POLR_ENTRY();
+	if (ranges_per_executor < 1 || ranges_per_executor > POLR_MORE_RANGES + 1) {
+		return POLR_E_INVALID;
+	}
+	return run_resident_impl(ms, stream, range_begin, range_end, n, out, flags, 0, 0, 0, false, ranges_per_executor);
 }
 
 int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,

@@ -297,6 +297,7 @@ struct ResidentSync {
 	} arrived[POLR_SLOTS][POLR_ARRIVE_SHARDS]; // per slot; monotonic across runs; the router sums the shards
 };
 
+#define POLR_MORE_RANGES 7 // polr_mpx_run_resident_ranges: up to 8 ranges per executor
 struct ResidentExec {
 	DevMpx *mpx;
 	ResidentSync *sync;
@@ -314,6 +315,11 @@ struct ResidentExec {
 	uint64_t morsel_end;
 	uint32_t morsel_chunks;
 	uint32_t path_plus1; // BACKPRESSURE: this executor sends everything down join order path_plus1 - 1 (0: as routed)
+	// further chunk ranges of this executor, routed one after the other behind [chunk_begin, chunk_end) with the same
+	// multiplexer state (polr_mpx_run_resident_ranges: a static list of morsels per executor)
+	uint32_t n_more;
+	uint32_t pad2;
+	uint64_t more_begin[POLR_MORE_RANGES], more_end[POLR_MORE_RANGES];
 };
 
 #define POLR_RES_HOT_DWORDS (offsetof(DevMpx, stage_out) / 4)

@@ -75,6 +75,13 @@ __device__ __forceinline__ void pool_load_exec(const ResidentExec *xp, ResidentE
 	x.morsel_end = uni64(xp->morsel_end);
 	x.morsel_chunks = uni(xp->morsel_chunks);
 	x.path_plus1 = uni(xp->path_plus1);
+	x.n_more = uni(xp->n_more);
+	x.pad2 = 0;
+#pragma unroll
+	for (int j = 0; j < POLR_MORE_RANGES; j++) {
+		x.more_begin[j] = uni64(xp->more_begin[j]);
+		x.more_end[j] = uni64(xp->more_end[j]);
+	}
 }
 
 // the router waves of a router workgroup; router_dwords: LDS dwords per router wave

@@ -549,6 +549,7 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	RT_T(rt_e3)
 	RT_ADD(10, rt_e3 - rt_entry)
 	uint32_t n_steps = 0;
+	uint32_t range_i = 0; // further ranges of this executor taken so far (ResidentExec::more_begin / more_end)
 	uint32_t n_pub = 0; // rounds published so far
 	uint32_t n_fly = 0; // published, counters not absorbed yet
 	PoolRoundOut ahead[POLR_SLOTS - 1] = {}; // the rehearsed rounds behind the front (statically indexed: registers)
@@ -641,6 +642,27 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			if (lane == 0) {
 				m->core.AddNumIntermediates(got);
 				m->num_intermediates_total += got;
+			}
+		}
+		if (!x.morsel_cursor && range_i < x.n_more) {
+			// this executor's current range is used up and it owns another one: go on there, same multiplexer state
+			const uint64_t ci = ((volatile DevMpx *)m)->chunk_idx, ce = ((volatile DevMpx *)m)->chunk_end;
+			if (ci >= ce) {
+				uint64_t nb = 0, ne = 0;
+#pragma unroll
+				for (uint32_t j = 0; j < POLR_MORE_RANGES; j++) {
+					if (j == range_i) {
+						nb = x.more_begin[j];
+						ne = x.more_end[j];
+					}
+				}
+				if (lane == 0) {
+					m->chunk_idx = nb;
+					m->chunk_end = ne;
+					m->done = nb >= ne ? 1 : 0;
+				}
+				range_i++;
+				__builtin_amdgcn_wave_barrier();
 			}
 		}
 		if (lane == 0 && x.morsel_cursor && m->chunk_idx >= m->chunk_end) {

@@ -31,7 +31,7 @@ EXPORTS = [
     "polr_out_create", "polr_out_reset", "polr_out_stats", "polr_out_fetch_ids", "polr_out_materialize",
     "polr_out_destroy", "polr_probe_rounds", "polr_probe_rounds_async",
     "polr_mpx_create", "polr_mpx_run", "polr_mpx_set_chunk_offsets", "polr_mpx_finish", "polr_mpx_fetch_log",
-    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_morsels",
+    "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_ranges", "polr_mpx_run_resident_morsels",
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
 ]
@@ -613,6 +613,22 @@ def run_resident(mpxs, ranges, out=None, reset=False, finish=False, share=1):
     e = np.ascontiguousarray([r[1] for r in ranges], dtype=np.uint64)
     ctx.check(ctx.L.polr_mpx_run_resident(hs, None, b.ctypes.data, e.ctypes.data, n, out.h if out else None,
                                           (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) | ((share & 0xFF) << 8 if share > 1 else 0)))
+
+
+def run_resident_ranges(mpxs, range_lists, out=None, reset=False, finish=False, share=1):
+    """polr_mpx_run_resident_ranges: range_lists[i] = [(begin, end), ...] of executor i (the same number for every one)"""
+    ctx = mpxs[0].ctx
+    n = len(mpxs)
+    r = len(range_lists[0])
+    hs = (C.c_void_p * n)(*[m.h for m in mpxs])
+    flat = [x for lst in range_lists for x in lst]
+    b = (C.c_uint64 * (n * r))(*[x[0] for x in flat])
+    e = (C.c_uint64 * (n * r))(*[x[1] for x in flat])
+    ctx.L.polr_mpx_run_resident_ranges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                  C.c_void_p, C.c_uint32]
+    ctx.check(ctx.L.polr_mpx_run_resident_ranges(hs, None, b, e, r, n, out.h if out else None,
+                                                 (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) |
+                                                 ((share & 0xFF) << 8 if share > 1 else 0)))
 
 
 def run_resident_morsels(mpxs, chunk_begin, chunk_end, morsel_chunks=120, out=None, reset=False, finish=False, share=1):

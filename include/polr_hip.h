@@ -393,6 +393,13 @@ int polr_mpx_run_many(polr_mpx **ms, void **streams, const uint64_t *chunk_begin
 #define POLR_RUN_SHARE(d) (((uint32_t)(d) & 0xFFu) << 8)
 int polr_mpx_run_resident(polr_mpx **ms, void *stream, const uint64_t *chunk_begin, const uint64_t *chunk_end,
                           uint32_t n, polr_out *out, uint32_t flags);
+/* The same with a LIST of chunk ranges per executor (range_begin / range_end: [n][ranges_per_executor], 1..8): executor i
+ * routes its ranges one after the other with one multiplexer state -- a worker thread that was handed several morsels
+ * up front.  Pairing a range from every part of a skewed table per executor evens out what the executors have to do
+ * (they finish together) and keeps runs reproducible, which a shared cursor does not. */
+int polr_mpx_run_resident_ranges(polr_mpx **ms, void *stream, const uint64_t *range_begin, const uint64_t *range_end,
+                                 uint32_t ranges_per_executor, uint32_t n, polr_out *out, uint32_t flags);
+
 /* Morsel-driven variant: the n executors SHARE the chunks [chunk_begin, chunk_end) and pull them `morsel_chunks`
  * chunks at a time from one device-side cursor -- the reference's worker threads pulling morsels from the
  * parallel scan state (a row group = 120 vectors; pipeline.cpp:145-174, table_scan.cpp) -- so a skewed source

@@ -236,3 +236,58 @@ def test_lip_rejects_a_dependent_join(gpu_ctx):
     with pytest.raises(capi.PolrError):
         pipe.scan_filter([], lip_joins=0b010)  # join 1 is keyed by a build column of join 0
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [2, 5])
+def test_executors_with_a_list_of_ranges(gpu_ctx, R):
+    """polr_mpx_run_resident_ranges: every executor routes R ranges (one out of each part of the source) one after the
+    other with ONE multiplexer state: COUNT(*) and the tuple total are the reference's, and an executor's trace is the
+    trace of a single executor handed the same list"""
+    from polr_amd import capi
+    wl, paths, c = workload("q4.1/3")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    k, P, E = len(wl["joins"]), len(paths), 7
+    lists = []
+    for e in range(E):
+        lst = []
+        for r in range(R):
+            lo, hi = (r * n_chunks) // R, ((r + 1) * n_chunks) // R
+            lst.append((lo + (e * (hi - lo)) // E, lo + ((e + 1) * (hi - lo)) // E))
+        lists.append(lst)
+    lists[3][0] = (lists[3][0][0], lists[3][0][0])  # an empty first range: its chunks go to the neighbour
+    covered = sum(b - a for lst in lists for a, b in lst)
+    mpxs = [capi.DeviceMultiplexer(pipe, "adaptive_reinit", max_log_rounds=1 << 14) for _ in range(E)]
+    capi.run_resident_ranges(mpxs, lists, reset=True, finish=True)
+    stats = capi.finish_many(mpxs)
+    routed = sum(sum(st["input_tuple_count_per_path"]) for st in stats)
+    # (executor 3 skipped its first range: count what was covered)
+    want_tuples = sum(min(b * 1024, n) - min(a * 1024, n) for lst in lists for a, b in lst)
+    assert routed == want_tuples and covered <= n_chunks
+    solo = capi.DeviceMultiplexer(pipe, "adaptive_reinit", max_log_rounds=1 << 14)
+    for e in (0, 3, E - 1):
+        capi.run_resident_ranges([solo], [lists[e]], reset=True, finish=True)
+        want = solo.finish()
+        _, _, want_log = solo.fetch_log()
+        _, _, got_log = mpxs[e].fetch_log()
+        assert list(got_log) == list(want_log) and stats[e]["num_intermediates"] == want["num_intermediates"]
+    # all ranges together (no gap): COUNT(*) is the reference's
+    full = []
+    for e in range(E):
+        lst = []
+        for r in range(R):
+            lo, hi = (r * n_chunks) // R, ((r + 1) * n_chunks) // R
+            lst.append((lo + (e * (hi - lo)) // E, lo + ((e + 1) * (hi - lo)) // E))
+        full.append(lst)
+    capi.run_resident_ranges(mpxs, full, reset=True, finish=True)
+    stats = capi.finish_many(mpxs)
+    assert sum(sum(st["stage_out"][p][k - 1] for p in range(P)) for st in stats) == c["count_star"]
+    assert sum(sum(st["input_tuple_count_per_path"]) for st in stats) == n
+    solo.close()
+    for m in mpxs:
+        m.close()
+    pipe.close()
