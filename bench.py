@@ -271,19 +271,36 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         # the path's one exchange step, in the product: polr_bcast_build (librccl, ncclBroadcast over xGMI) -- rank 0's
         # finalized tables to every rank.  torch.distributed only carries the 128-byte communicator id.
         # (POLR_DIST_BACKEND=gloo rehearsals on one GPU cannot form an RCCL communicator: they build locally)
-        if env.get("comm") is None and not env.get("comm_failed") and not os.environ.get("POLR_SHARE_DEVICE"):
+        if env.get("comm") is None and not env.get("comm_failed") and \
+                (not os.environ.get("POLR_SHARE_DEVICE") or os.environ.get("POLR_FORCE_COMM")):
             # (POLR_SHARE_DEVICE rehearsals put several ranks on one GPU, which RCCL refuses: they build locally)
             idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 idt.copy_(torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             ok = torch.ones(1, dtype=torch.int32)
-            try:
-                env["comm"] = capi.Comm(ctx, bytes(idt.numpy().tobytes()), world, rank)
-            except capi.PolrError as e:
+            # (ncclCommInitRank blocks until every rank has joined: on a thread of its own with a deadline, so that a
+            # bootstrap that cannot reach its peers costs two minutes, not the run)
+            import threading
+            box = {}
+
+            def _make():
+                try:
+                    box["comm"] = capi.Comm(ctx, bytes(idt.numpy().tobytes()), world, rank)
+                except capi.PolrError as e:
+                    box["err"] = str(e)
+
+            th = threading.Thread(target=_make, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("POLR_COMM_TIMEOUT_S", "120")))
+            if th.is_alive():
+                box["err"] = "ncclCommInitRank did not return within the deadline"
+            if "comm" in box and "err" not in box:
+                env["comm"] = box["comm"]
+            else:
                 # the measurement goes on with locally built tables (same bytes: the build is deterministic); the line
                 # says so -- the probe path itself is unaffected
-                env["comm_failed"] = str(e)
+                env["comm_failed"] = box.get("err", "communicator creation failed")
                 ok[0] = 0
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) == 0 and env.get("comm") is not None:
@@ -899,6 +916,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: RCCL's bootstrap over loopback (the container's hostname may not resolve)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         # control plane (rendezvous, the 128-byte communicator id, barriers, the max-over-ranks reduction): gloo.  The
         # data-path exchange -- the build sides -- goes over RCCL inside the library (polr_bcast_build, its own
         # communicator); torch's own RCCL (a second copy, on torch's bundled HIP runtime) is left out of the process
