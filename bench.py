@@ -205,12 +205,16 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     if is_ssb:
         query = SSB_QUERIES[name]
         z = ssb_skew.sizes(scale)
-        n_total = z["n_lo"] * (1 if args.strong else world)
+        # --strong: the ranks split ONE table of --scale (contiguous lo_orderkey ranges).  Otherwise (weak
+        # scaling) every rank probes a whole lineorder of --scale of its own: same dimension tables (built once,
+        # broadcast), same order keys / skew phases / load.sql rules, its own per-row draws (row_salt) -- the work
+        # per GPU is the work of the 1-GPU run
+        n_total = z["n_lo"]
         wl0 = ssb_skew.workload(query, sf=scale, n_lo=n_total, host_probe=False)
         inst = wl0["instance"]
-        lo, hi = pdist.probe_partition(n_total, world, rank, V)
+        lo, hi = pdist.probe_partition(n_total, world, rank, V) if args.strong else (0, n_total)
         names = list(ssb_skew.PROBE_COLS)
-        cols_t = inst.lineorder_torch(lo, hi, dev, cols=names)
+        cols_t = inst.lineorder_torch(lo, hi, dev, cols=names, row_salt=0 if args.strong else rank * (n_total + (-n_total) % 4))
         tens = [cols_t[c] for c in names]
         signed = [False] * len(names)
         n_rows = hi - lo
@@ -613,7 +617,10 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             "config": {"workload": desc, "routing": routing, "join_enumerator": enumerator,
                        "max_join_orders": args.max_join_orders, "join_orders": paths.tolist(), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
-                       "sink": "count(*)", "probe_partition_per_gpu": int(n_tuples), "executors_per_gpu": E, "device_share_of_the_launch": "1/%d" % max(P, pool_share),
+                       "sink": "count(*)", "probe_partition_per_gpu": int(n_tuples), "partitioning": ("strong: the ranks split one table, contiguous lo_orderkey ranges" if args.strong else
+                                        "weak: every rank probes a lineorder of its own of this shape (same dimension tables, "
+                                        "same skew phases, per-row draws salted by the rank)") if is_ssb else "per-rank seed",
+                       "executors_per_gpu": E, "device_share_of_the_launch": "1/%d" % max(P, pool_share),
                        "lip_joins": [wl0["joins"][x]["name"] for x in range(k) if (lip_mask >> x) & 1],
                        "launch": "pool (one launch per pass: %d router waves + shared probe waves)" % E,
                        "chunks_per_executor": ("morsels of %d" % args.morsels) if args.morsels > 0 else "fixed ranges",

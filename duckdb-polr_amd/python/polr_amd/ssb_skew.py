@@ -217,16 +217,22 @@ class Instance:
                 "load_sql_moduli_at_sf100": {"c1": 2942519, "c2": 59981, "c3": 2402, "s1": 183979, "s2": 787, "s3": 191}}
 
     # ---- lineorder rows [lo, hi): the base row, then load.sql's UPDATEs in order ----------------------------
-    def lineorder(self, lo, hi, xp=_NP, cols=("lo_custkey", "lo_suppkey", "lo_partkey", "lo_orderdate"), views=None):
+    def lineorder(self, lo, hi, xp=_NP, cols=("lo_custkey", "lo_suppkey", "lo_partkey", "lo_orderdate"), views=None,
+                  row_salt=0):
+        """row_salt (a multiple of 4): another lineorder of the same shape -- order keys, skew phases and the rules of
+        load.sql as for rows [lo, hi), the per-row random draws those of rows [lo + row_salt, hi + row_salt).  Rank r of
+        a weak-scaling run generates its own table with row_salt = r * n_lo: same work, different tuples."""
         s = _wrap(self.seed * 1000003)
         if views is None:
             views = self.device_views(xp)
         i = xp.arange(lo, hi)
         o = i >> 2
         okey = (o >> 3) * 32 + (o & 7) + 1
-        qty = 1 + _mix(xp, i, s + 31) % 50
-        cust = 1 + _mix(xp, o, s + 32) % self.n_c
-        supp = 1 + _mix(xp, i, s + 33) % self.n_s
+        ih = i + int(row_salt)
+        oh = o + (int(row_salt) >> 2)
+        qty = 1 + _mix(xp, ih, s + 31) % 50
+        cust = 1 + _mix(xp, oh, s + 32) % self.n_c
+        supp = 1 + _mix(xp, ih, s + 33) % self.n_s
         early = okey < self.t400
         late = okey >= self.t400
 
@@ -278,7 +284,7 @@ class Instance:
         if "lo_suppkey" in cols:
             out["lo_suppkey"] = xp.cast(supp, np.uint32)
         if "lo_partkey" in cols:
-            out["lo_partkey"] = xp.cast(1 + _mix(xp, i, s + 34) % self.n_p, np.uint32)
+            out["lo_partkey"] = xp.cast(1 + _mix(xp, ih, s + 34) % self.n_p, np.uint32)
         if "lo_orderdate" in cols:
             # load.sql:198-245: the year is a function of the order-key band, the day of lo_orderkey % 365
             doy = okey % 365
@@ -291,9 +297,9 @@ class Instance:
         if "lo_quantity" in cols:
             out["lo_quantity"] = xp.cast(qty, np.uint16)
         if "lo_revenue" in cols:
-            out["lo_revenue"] = xp.cast(100 + _mix(xp, i, s + 35) % 9900, np.uint32)
+            out["lo_revenue"] = xp.cast(100 + _mix(xp, ih, s + 35) % 9900, np.uint32)
         if "lo_supplycost" in cols:
-            out["lo_supplycost"] = xp.cast(50 + _mix(xp, i, s + 36) % 4950, np.uint32)
+            out["lo_supplycost"] = xp.cast(50 + _mix(xp, ih, s + 36) % 4950, np.uint32)
         return out
 
     def device_views(self, xp):
@@ -305,7 +311,7 @@ class Instance:
                 "dates": xp.asarray(dates)}
 
     def lineorder_torch(self, lo, hi, device, cols=("lo_custkey", "lo_suppkey", "lo_partkey", "lo_orderdate"),
-                        block=1 << 25):
+                        block=1 << 25, row_salt=0):
         """the same rows as torch tensors on `device`, generated there in blocks (int32 bit patterns of the uint32
         columns)"""
         import torch
@@ -315,7 +321,7 @@ class Instance:
                 for c in cols}
         for b in range(lo, hi, block):
             e = min(hi, b + block)
-            part = self.lineorder(b, e, xp, cols, views)
+            part = self.lineorder(b, e, xp, cols, views, row_salt=row_salt)
             for c in cols:
                 outs[c][b - lo:e - lo] = part[c]
         return outs

@@ -103,3 +103,20 @@ def test_workload_shape():
     assert all(len(c) == 100_000 for c in wl["probe"]["cols"].values())
     wl3 = ssb_skew.workload("q3.1", n_lo=10_000, n_c=30_000, n_s=20_000, n_p=20_000)
     assert len(wl3["joins"]) == 3
+
+
+def test_row_salt_gives_another_table_of_the_same_shape():
+    """weak scaling: rank r probes rows with row_salt = r * n_lo -- order keys, dates (a function of the order key) and
+    the skew rules stay, the per-row draws change; salt 0 is the table itself"""
+    inst = ssb_skew.workload("q4.1", sf=0.05, host_probe=False)["instance"]
+    n = min(inst.n_lo, 200_000)
+    cols = ("lo_orderkey", "lo_custkey", "lo_suppkey", "lo_partkey", "lo_orderdate")
+    a = inst.lineorder(0, n, cols=cols)
+    b = inst.lineorder(0, n, cols=cols, row_salt=0)
+    c = inst.lineorder(0, n, cols=cols, row_salt=4 * ((inst.n_lo + 3) // 4))
+    for k in cols:
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(a["lo_orderkey"], c["lo_orderkey"]) and np.array_equal(a["lo_orderdate"], c["lo_orderdate"])
+    assert (a["lo_partkey"] != c["lo_partkey"]).mean() > 0.9 and (a["lo_suppkey"] != c["lo_suppkey"]).mean() > 0.5
+    # the same four lines of an order share their customer in both tables
+    assert np.array_equal(c["lo_custkey"][0::4][: n // 4], c["lo_custkey"][1::4][: n // 4])
