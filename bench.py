@@ -749,6 +749,9 @@ def run_job_full(args, env, steps, warmup, with_cpu):
     stats = {}
 
     def step(fetch):
+        # (measured: running the pipelines side by side on shares of the device -- POLR_RUN_SHARE 4 / 8 / 16 -- is
+        # 15-60 % slower than one after the other; a few fan-out heavy pipelines carry the pass, and they want the
+        # whole device)
         for c in cases:
             capi.run_resident(c["mpxs"], c["ranges"], reset=True, finish=True)
         if fetch:
