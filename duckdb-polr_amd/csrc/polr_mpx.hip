@@ -672,7 +672,8 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 			const char *v = getenv("POLR_POOL_HI_UNIT");
 			return v ? atol(v) : 0l;
 		}();
-		// default: one step of the pipeline's stage 0 (flat: 512 tuples, generic: a wide step of 256).  64-tuple units
+		// default: flat: two steps of the pipeline's stage 0 (1 024 tuples = one exploration slice of init_tuple_count in one
+		// unit: measured 1.52 ms against 1.55-1.56 with 512 on the SF100 run), generic: a wide step of 256.  64-tuple units
 		// finish a lone small round soonest, but a unit costs its wave the same chain of dependent round trips whatever
 		// its size, and with hundreds of executors exploring that wave time is what the pool runs out of (measured on
 		// the SF100 run: 2.29 ms with 64-tuple units, 1.77 ms with 512)
@@ -689,7 +690,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 			}();
 			hr->hi_lottery = (lot_env >= 1 && (lot_env & (lot_env - 1)) == 0 && (uint32_t)lot_env <= lot) ? (uint32_t)lot_env : lot;
 		}
-		hr->hi_unit = hu_env >= 64 && hu_env <= 1024 && hu_env % 64 == 0 ? (uint32_t)hu_env : (flat ? 512u : 256u);
+		hr->hi_unit = hu_env >= 64 && hu_env <= 1024 && hu_env % 64 == 0 ? (uint32_t)hu_env : (flat ? 1024u : 256u);
 	}
 	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {
 		hr->worker_waves[r] = r < n_rings ? (pool_waves + n_rings - 1 - r) / n_rings : 0u; // (wave g serves ring g % n_rings)
