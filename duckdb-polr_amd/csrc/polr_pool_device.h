@@ -145,8 +145,9 @@ struct PoolRoundOut {
 	uint32_t begin, count, path, emit, unit, n_units, cls;
 };
 
-// unit size of a round: small rounds are spread 64 tuples per wave (the dependent-load chain of a step is the same
-// for 64 and for 512 tuples: more waves in parallel is strictly faster); big rounds are cut so that one executor's
+// unit size of a round: small rounds are cut into units of hi_unit tuples (PoolRun: 1 024 for the flat pipeline, 256 for
+// the generic one -- a unit costs its wave the same chain of dependent round trips whatever its size, and with hundreds
+// of executors exploring that wave time is what the pool runs out of); big rounds are cut so that one executor's
 // round gives every probe wave of its share of the pool a few units, in multiples of `gran` tuples
 __device__ __forceinline__ void polr_pool_size_units(uint64_t tuples64, uint32_t pool_waves, uint32_t n_exec, uint32_t gran,
                                                      uint32_t hi_tuples, uint32_t units_x, uint32_t hi_unit, bool terminal,
