@@ -371,10 +371,11 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     budget = args.regret_budget
     if routing == "exponential_backoff":
         budget = n_rows / 10240.0 / 10 / 1  # polar_config.cpp:115-120
-    # executors: 256 for table-sized sources; 32 for small ones -- except the strategies that decide every chunk
+    # executors: 384 for table-sized sources (SF100 Q4.1: 256 1.50-1.52 ms, 384 1.43-1.45, 448 1.38, 512 1.45; Q4.2 /
+    # Q4.3: 256 = 384, 512 slower); 32 for small ones -- except the strategies that decide every chunk
     # (one dependent routing round trip per chunk and executor: they want as many executors as the grid carries)
     per_chunk = routing in ("opportunistic", "dynamic")
-    want_e = args.executors if args.executors > 0 else (256 if n_chunks > 65536 else (640 if per_chunk else 32))
+    want_e = args.executors if args.executors > 0 else (384 if n_chunks > 65536 else (640 if per_chunk else 32))
     # a per-chunk strategy's rounds are a few hundred tuples each: half the grid probes them just as fast, and every
     # routing round trip (counter exchange, ticket, arrival) is quicker with half the idle waves polling (measured on
     # the JOB-light shape: OPPORTUNISTIC 4.9 -> 6.2 G tuples/s)
