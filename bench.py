@@ -204,17 +204,21 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     inst = None
     if is_ssb:
         query = SSB_QUERIES[name]
-        z = ssb_skew.sizes(scale)
-        # --strong: the ranks split ONE table of --scale (contiguous lo_orderkey ranges).  Otherwise (weak
-        # scaling) every rank probes a whole lineorder of --scale of its own: same dimension tables (built once,
-        # broadcast), same order keys / skew phases / load.sql rules, its own per-row draws (row_salt) -- the work
-        # per GPU is the work of the 1-GPU run
+        # N > 1 (BASELINE configs[4]): ONE table, contiguous lo_orderkey partitions, one per rank; the
+        # dimension tables are built on rank 0 and broadcast.  Default = weak scaling: the table is --scale x N (every rank
+        # probes 6 M x --scale rows; N = 8 at the default scale is SF800, the shape of configs[4]); --strong: the table is
+        # --scale, the ranks split it; --own-tables: every rank a whole lineorder of --scale of its own (same dimension
+        # tables, same order keys / skew phases / load.sql rules, its own per-row draws: row_salt)
+        one_table = world > 1 and not args.own_tables
+        total_scale = scale * world if (one_table and not args.strong) else scale
+        z = ssb_skew.sizes(total_scale)
         n_total = z["n_lo"]
-        wl0 = ssb_skew.workload(query, sf=scale, n_lo=n_total, host_probe=False)
+        wl0 = ssb_skew.workload(query, sf=total_scale, n_lo=n_total, host_probe=False)
         inst = wl0["instance"]
-        lo, hi = pdist.probe_partition(n_total, world, rank, V) if args.strong else (0, n_total)
+        lo, hi = pdist.probe_partition(n_total, world, rank, V) if one_table else (0, n_total)
         names = list(ssb_skew.PROBE_COLS)
-        cols_t = inst.lineorder_torch(lo, hi, dev, cols=names, row_salt=0 if args.strong else rank * (n_total + (-n_total) % 4))
+        cols_t = inst.lineorder_torch(lo, hi, dev, cols=names,
+                                      row_salt=0 if (one_table or world == 1) else rank * (n_total + (-n_total) % 4))
         tens = [cols_t[c] for c in names]
         signed = [False] * len(names)
         n_rows = hi - lo
@@ -275,16 +279,18 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         # the path's one exchange step, in the product: polr_bcast_build (librccl, ncclBroadcast over xGMI) -- rank 0's
         # finalized tables to every rank.  torch.distributed only carries the 128-byte communicator id.
         # (POLR_DIST_BACKEND=gloo rehearsals on one GPU cannot form an RCCL communicator: they build locally)
-        if env.get("comm") is None and not env.get("comm_failed") and \
-                (not os.environ.get("POLR_SHARE_DEVICE") or os.environ.get("POLR_FORCE_COMM")):
-            # (POLR_SHARE_DEVICE rehearsals put several ranks on one GPU, which RCCL refuses: they build locally)
+        share_dev = bool(os.environ.get("POLR_SHARE_DEVICE")) and not os.environ.get("POLR_FORCE_COMM")
+        if env.get("comm") is None and not share_dev:
+            # (POLR_SHARE_DEVICE rehearsals put several ranks on one GPU, which RCCL refuses: they -- and only they --
+            # build the deterministic tables on every rank)
             idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 idt.copy_(torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             ok = torch.ones(1, dtype=torch.int32)
-            # (ncclCommInitRank blocks until every rank has joined: on a thread of its own with a deadline, so that a
-            # bootstrap that cannot reach its peers costs two minutes, not the run)
+            # ncclCommInitRank blocks until every rank has joined: on a thread of its own with a deadline.  A missed
+            # deadline or a failure is FATAL for the multi-GPU run: every rank learns it through the all-reduce below,
+            # prints the reason and exits non-zero (os._exit: a thread may still be blocked inside RCCL)
             import threading
             box = {}
 
@@ -299,18 +305,15 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             th.join(timeout=float(os.environ.get("POLR_COMM_TIMEOUT_S", "120")))
             if th.is_alive():
                 box["err"] = "ncclCommInitRank did not return within the deadline"
-            if "comm" in box and "err" not in box:
-                env["comm"] = box["comm"]
-            else:
-                # the measurement goes on with locally built tables (same bytes: the build is deterministic); the line
-                # says so -- the probe path itself is unaffected
-                env["comm_failed"] = box.get("err", "communicator creation failed")
+            if "err" in box or "comm" not in box:
                 ok[0] = 0
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok[0]) == 0 and env.get("comm") is not None:
-                env["comm"].close()
-                env["comm"] = None
-                env["comm_failed"] = env.get("comm_failed") or "communicator creation failed on another rank"
+            if int(ok[0]) == 0:
+                print("bench.py rank %d: no RCCL communicator for polr_bcast_build (%s); a multi-GPU run without the "
+                      "build broadcast is not measured" % (rank, box.get("err", "another rank failed")),
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+            env["comm"] = box["comm"]
         comm = env.get("comm")
         if comm is not None:
             before = comm.bytes_broadcast()
@@ -322,6 +325,8 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                 got.append((ht, wl0["joins"][x]["key_src"]))
             joins = got
             bcast_bytes = comm.bytes_broadcast() - before
+            if bcast_bytes <= 0:
+                raise SystemExit("polr_bcast_build moved no bytes")
         elif rank != 0:
             joins = capi.build_joins(ctx, wl0, auto=not args.reference_tables)
         torch.cuda.synchronize()
@@ -604,7 +609,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         if is_ssb:
             desc = ("%s: SSB-skew %s at SF%g -- lineorder %d rows per GPU (rows %d..%d of %d, contiguous lo_orderkey "
                     "range) x %s; skew = benchmark/ssb-skew/init/load.sql:80-253 applied to synthetic SSB base tables, "
-                    "generated on the device" % (name, SSB_QUERIES[name], scale, n_rows, lo, hi, n_total,
+                    "generated on the device" % (name, SSB_QUERIES[name], total_scale, n_rows, lo, hi, n_total,
                                                  " x ".join("%s %d" % (j["name"], len(j["keys"][0])) for j in wl0["joins"])))
         else:
             desc = "%s (IMDB cardinalities x%.3g: %d probe tuples after the pushed-down filter; builds %s)" % (
@@ -612,15 +617,18 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         rec = {
             "metric": "probe-tuples/s", "value": round(value, 1), "unit": "tuples/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt_max / steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "u64",
             "dtype_note": "32-bit keys; hash / range arithmetic in 32/64-bit integers; f64 only in the reward",
             "data": "synthetic",
             "config": {"workload": desc, "routing": routing, "join_enumerator": enumerator,
                        "max_join_orders": args.max_join_orders, "join_orders": paths.tolist(), "chunk_size": V,
                        "regret_budget": args.regret_budget, "init_tuple_count": args.init_tuple_count,
-                       "sink": "count(*)", "probe_partition_per_gpu": int(n_tuples), "partitioning": ("strong: the ranks split one table, contiguous lo_orderkey ranges" if args.strong else
-                                        "weak: every rank probes a lineorder of its own of this shape (same dimension tables, "
-                                        "same skew phases, per-row draws salted by the rank)") if is_ssb else "per-rank seed",
+                       "sink": "count(*)", "probe_partition_per_gpu": int(n_tuples), "partitioning": (("one table of SF%g, contiguous lo_orderkey partitions, one per rank (%s)" % (
+                           total_scale, "strong: the table does not grow with N" if args.strong else
+                           "weak: the table is --scale x N")) if one_table else (
+                           "every rank probes a lineorder of its own of this shape (same dimension tables, same skew "
+                           "phases, per-row draws salted by the rank)" if world > 1 else "single rank: the whole table"))
+                       if is_ssb else "per-rank seed",
                        "executors_per_gpu": E, "device_share_of_the_launch": "1/%d" % max(P, pool_share),
                        "lip_joins": [wl0["joins"][x]["name"] for x in range(k) if (lip_mask >> x) & 1],
                        "launch": "pool (one launch per pass: %d router waves + shared probe waves)" % E,
@@ -632,7 +640,8 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
             "routing_rounds": int(st["num_rounds"]),
             "tuples_per_path": st["input_tuple_count_per_path"],
             "generate_s": round(t_gen, 3), "build_s": round(t_build, 3), "build_broadcast_bytes": int(bcast_bytes),
-            "build_broadcast": ("polr_bcast_build over RCCL" if bcast_bytes else (("built on every rank: " + str(env.get("comm_failed") or "ranks share one device")) if world > 1 else "single rank")),
+            "build_broadcast": ("polr_bcast_build over RCCL" if bcast_bytes else ("built on every rank: POLR_SHARE_DEVICE rehearsal, ranks share one device" if world > 1 else "single rank")),
+            "ranks_started": int(os.environ.get("POLR_RANKS_STARTED", "0")) or None,
             "roofline": roof, "cpu_baseline": cpu, "scan_filter": scan_info, "launch_info": info,
             "artefacts": artefacts,
             "timed_region": {"gpu": "routing + probing of every source chunk; probe key columns read from HBM inside the "
@@ -861,6 +870,44 @@ def run_job_full(args, env, steps, warmup, with_cpu):
     return rec
 
 
+def spawn_ranks(n, argv=None, script=None, extra_env=None):
+    """`python bench.py --gpus N` without a launcher: the parent -- which has made NO GPU call (torch.cuda.device_count()
+    does not initialise the runtime) -- starts N fresh rank processes of this script, one per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1), relays rank 0's JSON line and returns
+    non-zero if any rank does.  Never re-executes a process that touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "POLR_RANKS_STARTED": str(n)})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p_ in procs[1:]:
+        codes.append(p_.wait())
+    # ONE line on stdout: rank 0's JSON object (whatever else a library wrote there goes to stderr)
+    for line in out0.decode(errors="replace").splitlines():
+        if line.startswith("{"):
+            sys.stdout.write(line + "\n")
+        elif line.strip():
+            sys.stderr.write(line + "\n")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("bench.py: rank(s) %s exited non-zero" % ", ".join("%d (code %d)" % rc for rc in bad), file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     if os.environ.get("POLR_DIAG_TIMELINE"):
         from polr_amd import capi as _capi
@@ -876,6 +923,9 @@ def main():
                     help="SSB-skew: scale factor per GPU (default 100; with --strong: of the whole job); JOB shapes: "
                          "fraction of the IMDB cardinalities (default 1)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the ranks split ONE table of --scale")
+    ap.add_argument("--own-tables", action="store_true",
+                    help="N > 1, SSB-skew: every rank probes a whole lineorder of --scale of its own (per-row draws salted "
+                         "by the rank) instead of its partition of one table")
     ap.add_argument("--routing", default="adaptive_reinit")
     ap.add_argument("--enumerator", default="auto",
                     help="SET join_enumerator; auto = sample (the reference's default) for SSB-skew, each_last_once for "
@@ -922,10 +972,23 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves (nothing has touched the GPU in this process)
+        visible = torch.cuda.device_count()
+        if visible < args.gpus and not os.environ.get("POLR_SHARE_DEVICE"):
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (POLR_SHARE_DEVICE=1 rehearses several ranks on "
+                             "one device, without RCCL)" % (args.gpus, visible))
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        # stdout carries ONE JSON line (rank 0's): libraries that chat on fd 1 (gloo prints its connection summary there)
+        # are sent to stderr for the whole run; the line itself goes to the saved descriptor
+        sys.stdout.flush()
+        real_stdout = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = real_stdout
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             # one node: RCCL's bootstrap over loopback (the container's hostname may not resolve)
@@ -942,13 +1005,24 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d under a launcher with WORLD_SIZE %d: the two must agree" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from polr_amd import capi
     ctx = capi.Context(local_rank)  # raises without the HIP library / a gfx950 device: no fallback
+    # tuning sweeps (tools/sweep_*.sh): the library itself reads nothing from the environment -- the knobs travel through
+    # polr_ctx_set_pool_tuning
+    knobs = {}
+    for env_name, field in (("POLR_POOL_SHARE", "device_share"), ("POLR_POOL_UNITS_X", "units_x"),
+                            ("POLR_POOL_HI_UNIT", "hi_unit"), ("POLR_POOL_HI_LOTTERY", "hi_lottery"),
+                            ("POLR_POOL_HI_TUPLES", "hi_tuples"), ("POLR_POOL_IDLE_SLEEP", "idle_sleep"),
+                            ("POLR_POOL_WATCHDOG_US", "watchdog_us")):
+        if os.environ.get(env_name):
+            knobs[field] = int(os.environ[env_name])
+    if knobs:
+        ctx.set_pool_tuning(**knobs)
     env = {"torch": torch, "dist": dist, "dev": dev, "ctx": ctx, "world": world, "rank": rank}
     if args.workload == "job_full":
         head = run_job_full(args, env, args.steps, args.warmup, with_cpu=world == 1 and not args.no_cpu_baseline)

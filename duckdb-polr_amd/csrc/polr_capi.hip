@@ -95,6 +95,37 @@ int polr_ctx_sync(polr_ctx *ctx, void *stream) {
 	return POLR_OK;
 }
 
+int polr_ctx_set_pool_tuning(polr_ctx *ctx, const polr_pool_tuning *t) {
+	POLR_ENTRY();
+	if (!ctx) {
+		return POLR_E_INVALID;
+	}
+	if (!t) {
+		ctx->tuning = polr_pool_tuning {};
+		return POLR_OK;
+	}
+	if (t->device_share > 16) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "device share 1/%u: at most 16 runs side by side", t->device_share);
+	}
+	if (t->units_x > 4) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "units_x %u: 1..4 (ring capacities are sized for 4)", t->units_x);
+	}
+	if (t->hi_unit && (t->hi_unit < 64 || t->hi_unit > 1024 || t->hi_unit % 64)) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "hi_unit %u: 64..1024 in multiples of 64", t->hi_unit);
+	}
+	if (t->hi_lottery & (t->hi_lottery - 1)) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "hi_lottery %u: a power of two", t->hi_lottery);
+	}
+	if (t->idle_sleep && t->idle_sleep != 16 && t->idle_sleep != 64) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "idle_sleep %u: 16 or 64", t->idle_sleep);
+	}
+	if (t->reserved) {
+		return POLR_E_INVALID;
+	}
+	ctx->tuning = *t;
+	return POLR_OK;
+}
+
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------------
@@ -1178,6 +1209,33 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "probe side of %llu rows exceeds the 32-bit row-id space per shard",
 		          (unsigned long long)n_probe_rows);
 	}
+	// the descriptors first: the dependency walk below reads n_keys / n_preds entries of every join and shifts by the
+	// join index a key or a condition names
+	for (uint32_t j = 0; j < k; j++) {
+		const polr_ht *ht = joins[j].ht;
+		if (!ht || ht->kind == KIND_NONE) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "join %u: build side not finalized", j);
+		}
+		if (joins[j].n_keys != ht->n_keys || joins[j].n_keys < 1 || joins[j].n_keys > POLR_MAX_KEYS) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "join %u: %u probe keys for a %u-key table", j, joins[j].n_keys, ht->n_keys);
+		}
+		if (joins[j].n_preds > POLR_MAX_PREDS) {
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u: %u non-equality conditions (at most %d)", j, joins[j].n_preds,
+			          POLR_MAX_PREDS);
+		}
+		for (uint32_t c = 0; c < joins[j].n_keys; c++) {
+			const int32_t sj = joins[j].key_src_join[c];
+			if (sj >= 0 && ((uint32_t)sj >= k || (uint32_t)sj == j)) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "join %u key %u: reads a build column of join %d", j, c, sj);
+			}
+		}
+		for (uint32_t c = 0; c < joins[j].n_preds; c++) {
+			const int32_t sj = joins[j].pred_src_join[c];
+			if (sj >= 0 && ((uint32_t)sj >= k || (uint32_t)sj == j)) {
+				POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: reads a build column of join %d", j, c, sj);
+			}
+		}
+	}
 	// every path must be a permutation of 0..k-1 that respects the key dependencies
 	// (POLARConfig join_prerequisites, polar_config.cpp:72-95)
 	for (uint32_t p = 0; p < n_paths; p++) {
@@ -1194,7 +1252,7 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 					          sj);
 				}
 			}
-			for (uint32_t c = 0; c < joins[x].n_preds && c < POLR_MAX_PREDS; c++) {
+			for (uint32_t c = 0; c < joins[x].n_preds; c++) {
 				const int32_t sj = joins[x].pred_src_join[c];
 				if (sj >= 0 && !((seen >> sj) & 1)) {
 					POLR_FAIL(ctx, POLR_E_INVALID, "path %u probes join %d before join %d that a condition of it reads", p, x,

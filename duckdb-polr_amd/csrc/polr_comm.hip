@@ -17,8 +17,8 @@
 
 namespace {
 
-// the five RCCL entry points used (rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220, ncclCommDestroy :260,
-// ncclGetErrorString :339, ncclBroadcast :591)
+// the six RCCL entry points used (rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220, ncclCommDestroy :260,
+// ncclGetErrorString :339, ncclBroadcast :591, ncclAllReduce :611)
 typedef struct {
 	char internal[POLR_COMM_ID_BYTES];
 } rccl_unique_id;
@@ -28,7 +28,11 @@ typedef int (*fn_comm_init_rank)(rccl_comm_t *, int, rccl_unique_id, int);
 typedef int (*fn_comm_destroy)(rccl_comm_t);
 typedef const char *(*fn_get_error_string)(int);
 typedef int (*fn_broadcast)(const void *, void *, size_t, int /* ncclDataType_t */, int, rccl_comm_t, hipStream_t);
-enum { RCCL_UINT8 = 1 }; // ncclUint8 (rccl.h: ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1)
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int /* ncclDataType_t */, int /* ncclRedOp_t */, rccl_comm_t,
+                             hipStream_t);
+typedef int (*fn_comm_abort)(rccl_comm_t);
+enum { RCCL_UINT8 = 1, RCCL_INT32 = 2 }; // rccl.h:459-462: ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2
+enum { RCCL_MIN = 3 };                   // rccl.h:448-451: ncclSum 0, ncclProd 1, ncclMax 2, ncclMin 3
 
 struct Rccl {
 	void *lib = nullptr;
@@ -37,6 +41,8 @@ struct Rccl {
 	fn_comm_destroy comm_destroy = nullptr;
 	fn_get_error_string get_error_string = nullptr;
 	fn_broadcast broadcast = nullptr;
+	fn_all_reduce all_reduce = nullptr;
+	fn_comm_abort comm_abort = nullptr; // (optional)
 	std::string err;
 };
 
@@ -61,7 +67,10 @@ Rccl &rccl() {
 		x.comm_destroy = (fn_comm_destroy)dlsym(x.lib, "ncclCommDestroy");
 		x.get_error_string = (fn_get_error_string)dlsym(x.lib, "ncclGetErrorString");
 		x.broadcast = (fn_broadcast)dlsym(x.lib, "ncclBroadcast");
-		if (!x.get_unique_id || !x.comm_init_rank || !x.comm_destroy || !x.get_error_string || !x.broadcast) {
+		x.all_reduce = (fn_all_reduce)dlsym(x.lib, "ncclAllReduce");
+		x.comm_abort = (fn_comm_abort)dlsym(x.lib, "ncclCommAbort");
+		if (!x.get_unique_id || !x.comm_init_rank || !x.comm_destroy || !x.get_error_string || !x.broadcast ||
+		    !x.all_reduce) {
 			x.err = "librccl.so lacks a symbol of the NCCL API";
 		}
 		return x;
@@ -75,7 +84,7 @@ struct polr_comm {
 	polr_ctx *ctx = nullptr;
 	rccl_comm_t comm = nullptr;
 	int world = 1, rank = 0;
-	unsigned long long *scratch = nullptr; // device: [0] = size of the metadata blob; then the blob (4 KB)
+	unsigned long long *scratch = nullptr; // device: [0] = size of the metadata blob; then the blob; behind it a status word
 	uint64_t bytes_broadcast = 0;
 };
 #define POLR_COMM_SCRATCH 8192
@@ -129,7 +138,7 @@ int polr_comm_create(polr_ctx *ctx, const void *id, int world_size, int rank, po
 		delete c;
 		POLR_FAIL(ctx, POLR_E_HIP, "ncclCommInitRank failed: %s", r.get_error_string(rc));
 	}
-	hipError_t e = hipMalloc((void **)&c->scratch, POLR_COMM_SCRATCH);
+	hipError_t e = hipMalloc((void **)&c->scratch, POLR_COMM_SCRATCH + 64); // (+ the status word of polr_bcast_build)
 	if (e != hipSuccess) {
 		r.comm_destroy(c->comm);
 		polr_ctx_release(c->ctx);
@@ -142,73 +151,127 @@ int polr_comm_create(polr_ctx *ctx, const void *id, int world_size, int rank, po
 
 // root: *ht is the finalized table to send (unchanged).  Every other rank: *ht receives a new table of the same shape,
 // owned by the caller (polr_ht_destroy).  Collective: every rank of the communicator calls it, in the same order.
+//
+// Failures are collective too: whatever goes wrong on ONE rank before the table buffers travel -- the root has no
+// finalized table, its export fails or its metadata does not fit the scratch block; a receiver cannot allocate the
+// table or reads metadata that make no sense -- every rank still runs the same sequence of collectives
+//   (1) broadcast of the metadata block   (size 0 = "the root has nothing to send")
+//   (2) all-reduce (min) of one status word per rank, after every rank has its table and its buffer list
+//   (3) one broadcast per table buffer, only when the status of every rank is 1
+// and every rank returns an error from the same step; nobody is left blocked inside a collective the others never
+// enter.  (A failing RCCL or HIP call itself is not recoverable this way: the communicator is then unusable.)
 int polr_bcast_build(polr_comm *comm, polr_ht **ht, int root, void *stream) {
 	POLR_ENTRY();
 	if (!comm || !ht || root < 0 || root >= comm->world) {
-		return POLR_E_INVALID;
+		return POLR_E_INVALID; // (a caller bug, the same on every rank: arguments are checked before anything travels)
 	}
 	polr_ctx *ctx = comm->ctx;
 	Rccl &r = rccl();
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = polr_stream(ctx, stream);
 	const bool is_root = comm->rank == root;
-	if (is_root && (!*ht || (*ht)->kind == KIND_NONE)) {
-		POLR_FAIL(ctx, POLR_E_INVALID, "broadcast root has no finalized build side");
-	}
+	int local_rc = POLR_OK;
+	std::string local_msg;
+	auto fail_local = [&](int rc, const std::string &msg) {
+		if (local_rc == POLR_OK) {
+			local_rc = rc;
+			local_msg = msg;
+		}
+	};
 	// (1) the metadata blob: its size, then the bytes
 	std::vector<uint8_t> meta;
 	unsigned long long meta_bytes = 0;
 	if (is_root) {
-		uint64_t mb = 0;
-		uint32_t nb = 0;
-		int rc = polr_ht_export(*ht, nullptr, &mb, nullptr, nullptr, &nb);
-		if (rc) {
-			return rc;
-		}
-		meta.resize(mb);
-		std::vector<void *> ptrs(nb);
-		std::vector<uint64_t> sizes(nb);
-		rc = polr_ht_export(*ht, meta.data(), &mb, ptrs.data(), sizes.data(), &nb);
-		if (rc) {
-			return rc;
-		}
-		meta_bytes = mb;
-		if (mb + 8 > POLR_COMM_SCRATCH) {
-			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "build-side metadata of %llu bytes", meta_bytes);
+		if (!*ht || (*ht)->kind == KIND_NONE) {
+			fail_local(POLR_E_INVALID, "broadcast root has no finalized build side");
+		} else {
+			uint64_t mb = 0;
+			uint32_t nb = 0;
+			int rc = polr_ht_export(*ht, nullptr, &mb, nullptr, nullptr, &nb);
+			if (!rc) {
+				meta.resize(mb);
+				std::vector<void *> ptrs0(nb);
+				std::vector<uint64_t> sizes0(nb);
+				rc = polr_ht_export(*ht, meta.data(), &mb, ptrs0.data(), sizes0.data(), &nb);
+			}
+			if (rc) {
+				fail_local(rc, std::string("export of the build side failed: ") + polr_last_error(ctx));
+			} else if (mb == 0 || mb + 8 > POLR_COMM_SCRATCH) {
+				fail_local(POLR_E_UNSUPPORTED, "build-side metadata of " + std::to_string(mb) + " bytes");
+			} else {
+				meta_bytes = mb;
+			}
 		}
 		HIPCHK(ctx, hipMemcpyAsync(comm->scratch, &meta_bytes, 8, hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(comm->scratch + 1, meta.data(), mb, hipMemcpyHostToDevice, st));
+		if (meta_bytes) {
+			HIPCHK(ctx, hipMemcpyAsync(comm->scratch + 1, meta.data(), meta_bytes, hipMemcpyHostToDevice, st));
+		}
 	}
 	RCCLCHK(ctx, r.broadcast(comm->scratch, comm->scratch, POLR_COMM_SCRATCH, RCCL_UINT8, root, comm->comm, st));
+	polr_ht *fresh = nullptr;
 	if (!is_root) {
 		HIPCHK(ctx, hipMemcpyAsync(&meta_bytes, comm->scratch, 8, hipMemcpyDeviceToHost, st));
 		HIPCHK(ctx, hipStreamSynchronize(st));
-		if (meta_bytes == 0 || meta_bytes + 8 > POLR_COMM_SCRATCH) {
-			POLR_FAIL(ctx, POLR_E_HIP, "broadcast metadata corrupt (%llu bytes)", meta_bytes);
-		}
-		meta.resize(meta_bytes);
-		HIPCHK(ctx, hipMemcpy(meta.data(), comm->scratch + 1, meta_bytes, hipMemcpyDeviceToHost));
-		polr_ht *fresh = nullptr;
-		int rc = polr_ht_alloc_like(ctx, meta.data(), meta_bytes, &fresh);
-		if (rc) {
-			return rc;
-		}
-		*ht = fresh;
 	}
-	// (2) every device buffer of the table, in place
+	if (meta_bytes == 0) {
+		// the root had nothing to send: every rank leaves here, after the one collective all of them have entered
+		if (is_root) {
+			POLR_FAIL(ctx, local_rc, "%s", local_msg.c_str());
+		}
+		POLR_FAIL(ctx, POLR_E_INVALID, "the broadcast root (rank %d) has no build side to send", root);
+	}
+	if (!is_root) {
+		if (meta_bytes + 8 > POLR_COMM_SCRATCH) {
+			fail_local(POLR_E_HIP, "broadcast metadata corrupt (" + std::to_string(meta_bytes) + " bytes)");
+		} else {
+			meta.resize(meta_bytes);
+			HIPCHK(ctx, hipMemcpy(meta.data(), comm->scratch + 1, meta_bytes, hipMemcpyDeviceToHost));
+			int rc = polr_ht_alloc_like(ctx, meta.data(), meta_bytes, &fresh);
+			if (rc) {
+				fresh = nullptr;
+				fail_local(rc, std::string("receiving table: ") + polr_last_error(ctx));
+			}
+		}
+	}
+	// the buffer list of this rank's table (the root's own, a receiver's fresh one)
+	polr_ht *mine = is_root ? *ht : fresh;
 	uint64_t mb = 0;
 	uint32_t nb = 0;
-	int rc = polr_ht_export(*ht, nullptr, &mb, nullptr, nullptr, &nb);
-	if (rc) {
-		return rc;
+	std::vector<void *> ptrs;
+	std::vector<uint64_t> sizes;
+	if (mine) {
+		int rc = polr_ht_export(mine, nullptr, &mb, nullptr, nullptr, &nb);
+		if (!rc) {
+			std::vector<uint8_t> meta2(mb);
+			ptrs.resize(nb);
+			sizes.resize(nb);
+			rc = polr_ht_export(mine, meta2.data(), &mb, ptrs.data(), sizes.data(), &nb);
+		}
+		if (rc) {
+			fail_local(rc, std::string("buffer list of the table: ") + polr_last_error(ctx));
+		}
 	}
-	std::vector<uint8_t> meta2(mb);
-	std::vector<void *> ptrs(nb);
-	std::vector<uint64_t> sizes(nb);
-	rc = polr_ht_export(*ht, meta2.data(), &mb, ptrs.data(), sizes.data(), &nb);
-	if (rc) {
-		return rc;
+	// (2) agree: 1 only if every rank is ready for the buffers
+	int status = local_rc == POLR_OK ? 1 : 0;
+	int *status_dev = (int *)((uint8_t *)comm->scratch + POLR_COMM_SCRATCH);
+	HIPCHK(ctx, hipMemcpyAsync(status_dev, &status, sizeof(int), hipMemcpyHostToDevice, st));
+	RCCLCHK(ctx, r.all_reduce(status_dev, status_dev, 1, RCCL_INT32, RCCL_MIN, comm->comm, st));
+	int agreed = 0;
+	HIPCHK(ctx, hipMemcpyAsync(&agreed, status_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	if (agreed != 1) {
+		if (fresh) {
+			polr_ht_destroy(fresh);
+		}
+		if (local_rc != POLR_OK) {
+			POLR_FAIL(ctx, local_rc, "%s", local_msg.c_str());
+		}
+		POLR_FAIL(ctx, POLR_E_HIP, "another rank could not take part in the broadcast of this build side");
 	}
+	if (!is_root) {
+		*ht = fresh;
+	}
+	// (3) every device buffer of the table, in place
 	for (uint32_t i = 0; i < nb; i++) {
 		if (sizes[i] == 0) {
 			continue;

@@ -123,20 +123,16 @@ DECL_K(4)
 DECL_K(6)
 DECL_K(8)
 struct PoolRun;
-// (POLR_EXT builds of the generic pool kernel: 4 and 8 compiled stages only)
-#define DECL_POOL_X(KK)                                                                                                \
-	int polr_pool_occupancy_k##KK##x(uint32_t W, uint32_t waves_per_block);                                           \
-	hipError_t polr_launch_pool_kernel_k##KK##x(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,              \
-	                                            hipStream_t stream, const DevPipeline *pipe,                         \
-	                                            const ResidentExec *execs, PoolRun *run, DevOut out);
-DECL_POOL_X(4)
-DECL_POOL_X(8)
+// the generic pipeline's pool kernel (polr_poolg.hip; the build with packed composite keys / conditions: ...x)
+uint32_t polr_poolg_waves_per_block(uint32_t k, uint32_t W);
+size_t polr_poolg_lds_bytes(uint32_t k, uint32_t W);
+int polr_poolg_occupancy(uint32_t k, uint32_t W);
+int polr_poolg_occupancyx(uint32_t k, uint32_t W);
+hipError_t polr_launch_poolg_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, hipStream_t stream, const DevPipeline *pipe,
+                                    const ResidentExec *execs, PoolRun *run, DevOut out);
+hipError_t polr_launch_poolg_kernelx(uint32_t W, uint32_t k, uint32_t n_blocks, hipStream_t stream, const DevPipeline *pipe,
+                                     const ResidentExec *execs, PoolRun *run, DevOut out);
 #define DECL_POOL_K(KK)                                                                                                \
-	size_t polr_pool_lds_bytes_k##KK(uint32_t W, uint32_t waves_per_block);                                           \
-	int polr_pool_occupancy_k##KK(uint32_t W, uint32_t waves_per_block);                                              \
-	hipError_t polr_launch_pool_kernel_k##KK(uint32_t W, uint32_t n_blocks, uint32_t waves_per_block,                 \
-	                                         hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs, \
-	                                         PoolRun *run, DevOut out);                                              \
 	size_t polr_pool_flat_lds_bytes_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                           \
 	size_t polr_pool_flat_wave_bytes_k##KK();                                                                         \
 	int polr_pool_flat_occupancy_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                              \
@@ -211,31 +207,25 @@ extern "C++" hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t
 		return call8;                                                                                                  \
 	}
 
-extern "C++" size_t polr_pool_lds_bytes(uint32_t k, uint32_t W, uint32_t wpb) {
-	POOL_SWITCH(k, polr_pool_lds_bytes_k2(W, wpb), polr_pool_lds_bytes_k4(W, wpb), polr_pool_lds_bytes_k6(W, wpb),
-	            polr_pool_lds_bytes_k8(W, wpb))
+// the generic pipeline's pool kernel: one kernel per carried-slot count W, the join count is a run-time value
+extern "C++" uint32_t polr_pool_waves_per_block(uint32_t k, uint32_t W) {
+	return polr_poolg_waves_per_block(k, W);
 }
 
-// ext: the pipeline has stages with an extension record (DevPipeline::ext) -> the POLR_EXT build of the generic kernel
-extern "C++" int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t wpb, bool ext) {
-	if (ext) {
-		return k <= 4 ? polr_pool_occupancy_k4x(W, wpb) : polr_pool_occupancy_k8x(W, wpb);
-	}
-	POOL_SWITCH(k, polr_pool_occupancy_k2(W, wpb), polr_pool_occupancy_k4(W, wpb), polr_pool_occupancy_k6(W, wpb),
-	            polr_pool_occupancy_k8(W, wpb))
+extern "C++" size_t polr_pool_lds_bytes(uint32_t k, uint32_t W) {
+	return polr_poolg_lds_bytes(k, W);
 }
 
-extern "C++" hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t wpb, hipStream_t stream,
+// ext: the pipeline has stages with an extension record (DevPipeline::ext) -> the POLR_EXT build of the kernel
+extern "C++" int polr_pool_occupancy(uint32_t k, uint32_t W, bool ext) {
+	return ext ? polr_poolg_occupancyx(k, W) : polr_poolg_occupancy(k, W);
+}
+
+extern "C++" hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, hipStream_t stream,
                                                 const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run,
                                                 DevOut out, bool ext) {
-	if (ext) {
-		return k <= 4 ? polr_launch_pool_kernel_k4x(W, n_blocks, wpb, stream, pipe, execs, run, out)
-		              : polr_launch_pool_kernel_k8x(W, n_blocks, wpb, stream, pipe, execs, run, out);
-	}
-	POOL_SWITCH(k, polr_launch_pool_kernel_k2(W, n_blocks, wpb, stream, pipe, execs, run, out),
-	            polr_launch_pool_kernel_k4(W, n_blocks, wpb, stream, pipe, execs, run, out),
-	            polr_launch_pool_kernel_k6(W, n_blocks, wpb, stream, pipe, execs, run, out),
-	            polr_launch_pool_kernel_k8(W, n_blocks, wpb, stream, pipe, execs, run, out))
+	return ext ? polr_launch_poolg_kernelx(W, k, n_blocks, stream, pipe, execs, run, out)
+	           : polr_launch_poolg_kernel(W, k, n_blocks, stream, pipe, execs, run, out);
 }
 
 extern "C++" size_t polr_pool_flat_lds_bytes(uint32_t k, uint32_t wpb, uint32_t table_dwords) {

@@ -24,6 +24,7 @@ struct polr_ctx {
 	std::string err;
 	std::atomic<int> refs {1};
 	bool closed = false; // polr_ctx_destroy was called: the stream is gone, the object lives on for its children
+	polr_pool_tuning tuning {}; // polr_ctx_set_pool_tuning (all zero: defaults)
 };
 
 static inline polr_ctx *polr_ctx_retain(polr_ctx *ctx) {
@@ -155,10 +156,11 @@ hipError_t polr_launch_path_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, ui
                                    DevOut out, unsigned long long *counts, SelfRoute sr);
 // the whole run in one launch (polr_pool.hip): routers + a pool of probe waves
 struct PoolRun;
-size_t polr_pool_lds_bytes(uint32_t k, uint32_t W, uint32_t waves_per_block);
-int polr_pool_occupancy(uint32_t k, uint32_t W, uint32_t waves_per_block, bool ext);
-hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, hipStream_t stream,
-                                   const DevPipeline *pipe, const ResidentExec *execs, PoolRun *run, DevOut out, bool ext);
+uint32_t polr_pool_waves_per_block(uint32_t k, uint32_t W); // 0: does not fit at all
+size_t polr_pool_lds_bytes(uint32_t k, uint32_t W);
+int polr_pool_occupancy(uint32_t k, uint32_t W, bool ext);
+hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, hipStream_t stream, const DevPipeline *pipe,
+                                   const ResidentExec *execs, PoolRun *run, DevOut out, bool ext);
 size_t polr_pool_flat_lds_bytes(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
 size_t polr_pool_flat_wave_bytes(uint32_t k);
 int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);

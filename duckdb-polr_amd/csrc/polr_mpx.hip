@@ -61,6 +61,7 @@ struct polr_mpx {
 	PoolSync *pool_dev = nullptr;      // unit rings of the runs this multiplexer leads
 	uint32_t pool_lo_cap = 0, pool_hi_cap = 0;
 	bool pool_dirty = false;           // a run was given up: rings and tickets are re-initialised before the next one
+	polr_mpx *leader = nullptr;        // the first multiplexer of the last pool run this one took part in (owns the rings)
 	uint32_t res_epoch = 0;
 	polr_mpx_stats *stats_host = nullptr; // pinned, mapped: closing statistics of a POLR_RUN_FINISH run
 	polr_mpx_stats *stats_host_dev = nullptr;
@@ -292,16 +293,16 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
 	const bool mat = materialize != 0;
 	const DevPipeline &dp = mat ? p->host_mat : p->host_count;
 	const bool flat = !mat && dp.flat != 0;
-	const uint32_t wpb = flat ? p->flat_wpb : polr_waves_per_block(p, mat);
-	if (wpb == 0) {
-		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
-	}
+	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, dp.W);
 	memset(info, 0, sizeof(*info));
 	info->waves_per_workgroup = wpb;
-	const int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb, dp.ext != 0);
+	const int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, dp.ext != 0));
+	if (occ < 1) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
+	}
 	info->workgroups_per_cu = (uint32_t)std::max(0, std::min(occ, 8));
 	info->lds_bytes_per_workgroup = (uint32_t)(flat ? polr_pool_flat_lds_bytes(dp.k, wpb, dp.lds_table_dwords)
-	                                                : polr_pool_lds_bytes(dp.k, dp.W, wpb));
+	                                                : polr_pool_lds_bytes(dp.k, dp.W));
 	info->compiled_stages = dp.k <= 2 ? 2 : (dp.k <= 4 ? 4 : (dp.k <= 6 ? 6 : 8));
 	info->tuple_slots = dp.W;
 	info->n_cus = (uint32_t)ctx->n_cus;
@@ -569,25 +570,15 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	const bool materialize = out != nullptr;
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
 	const bool flat = !materialize && dp.flat != 0;
-	const uint32_t wpb = flat ? p->flat_wpb : polr_waves_per_block(p, materialize);
-	if (wpb == 0) {
-		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
-	}
-	int occ = flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, wpb, dp.ext != 0);
+	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, dp.W);
+	int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, dp.ext != 0));
 	if (occ < 1) {
-		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel does not fit on a CU");
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "pool kernel does not fit on a CU (per-wave LDS queues: too many joins x carried ids)");
 	}
 	occ = std::min(occ, 8);
 	uint32_t share = std::max<uint32_t>((flags >> 8) & 0xFFu, 1u);
-	{
-		// (tuning knob: POLR_POOL_SHARE in the environment sizes the grid for 1/share of the device)
-		static const long share_env = [] {
-			const char *v = getenv("POLR_POOL_SHARE");
-			return v ? atol(v) : 0l;
-		}();
-		if (share_env > 0) {
-			share = (uint32_t)share_env;
-		}
+	if (ctx->tuning.device_share) { // (polr_ctx_set_pool_tuning)
+		share = ctx->tuning.device_share;
 	}
 	if (share > 16) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "device share 1/%u: at most 16 runs side by side", share);
@@ -635,6 +626,13 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	                                              (uint64_t)POLR_SLOTS * n + pool_waves / R + 16) + 64);
 	const uint32_t hi_cap =
 	    next_pow2_u32(2ull * ((uint64_t)POLR_SLOTS * n * (POLR_POOL_HI_TUPLES / POLR_POOL_HI_UNIT / R + 1)) + 64);
+	if (((volatile uint32_t *)m0->done_host)[2]) {
+		// an earlier run on these rings was given up (whoever finished it): probe waves left holding tickets
+		m0->pool_dirty = true;
+		if (!m0->pending_sync) {
+			((volatile uint32_t *)m0->done_host)[2] = 0; // (nothing in flight that could still report it)
+		}
+	}
 	if (!m0->pool_dev || m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap || m0->pool_dirty) {
 		if (m0->pool_dev && (m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap)) {
 			HIPCHK(ctx, hipStreamSynchronize(st));
@@ -661,18 +659,10 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hr->n_router_blocks = n_router_blocks;
 	hr->n_rings = n_rings;
 	{
-		// (tuning knob: POLR_POOL_UNITS_X in the environment, 1..4)
-		static const long ux_env = [] {
-			const char *v = getenv("POLR_POOL_UNITS_X");
-			return v ? atol(v) : 0l;
-		}();
-		hr->units_x = ux_env >= 1 && ux_env <= 4 ? (uint32_t)ux_env : 4u; // (ring capacities are sized for 4)
-		// (tuning knob: POLR_POOL_HI_UNIT, tuples per unit of a small round: 64 .. 1024, a multiple of 64)
-		static const long hu_env = [] {
-			const char *v = getenv("POLR_POOL_HI_UNIT");
-			return v ? atol(v) : 0l;
-		}();
-		// default: flat: two steps of the pipeline's stage 0 (1 024 tuples = one exploration slice of init_tuple_count in one
+		const polr_pool_tuning &tn = ctx->tuning; // (polr_ctx_set_pool_tuning; 0 = default)
+		hr->units_x = tn.units_x ? tn.units_x : 4u; // (ring capacities are sized for 4)
+		// tuples per unit of a small round.  Default: flat: two steps of the pipeline's stage 0 (1 024 tuples = one
+		// exploration slice of init_tuple_count in one
 		// unit: measured 1.52 ms against 1.55-1.56 with 512 on the SF100 run), generic: a wide step of 256.  64-tuple units
 		// finish a lone small round soonest, but a unit costs its wave the same chain of dependent round trips whatever
 		// its size, and with hundreds of executors exploring that wave time is what the pool runs out of (measured on
@@ -684,13 +674,9 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 			while (lot * 2 <= std::min<uint32_t>(8, min_waves)) {
 				lot *= 2;
 			}
-			static const long lot_env = [] {
-				const char *v = getenv("POLR_POOL_HI_LOTTERY");
-				return v ? atol(v) : 0l;
-			}();
-			hr->hi_lottery = (lot_env >= 1 && (lot_env & (lot_env - 1)) == 0 && (uint32_t)lot_env <= lot) ? (uint32_t)lot_env : lot;
+			hr->hi_lottery = (tn.hi_lottery >= 1 && tn.hi_lottery <= lot) ? tn.hi_lottery : lot;
 		}
-		hr->hi_unit = hu_env >= 64 && hu_env <= 1024 && hu_env % 64 == 0 ? (uint32_t)hu_env : (flat ? 1024u : 256u);
+		hr->hi_unit = tn.hi_unit ? tn.hi_unit : (flat ? 1024u : 256u);
 	}
 	for (uint32_t r = 0; r < POLR_POOL_RINGS; r++) {
 		hr->worker_waves[r] = r < n_rings ? (pool_waves + n_rings - 1 - r) / n_rings : 0u; // (wave g serves ring g % n_rings)
@@ -698,27 +684,20 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hr->pool_waves = pool_waves;
 	hr->lo_cap = m0->pool_lo_cap;
 	hr->hi_cap = m0->pool_hi_cap;
-	{
-		// (tuning knob: POLR_POOL_HI_TUPLES in the environment overrides the size up to which a round is latency-critical)
-		static const long hi_env = [] {
-			const char *v = getenv("POLR_POOL_HI_TUPLES");
-			return v ? atol(v) : -1l;
-		}();
-		hr->hi_tuples = hi_env >= 0 ? (uint32_t)std::min<long>(hi_env, POLR_POOL_HI_TUPLES) : POLR_POOL_HI_TUPLES;
-	}
-	{
-		// (tuning knob: POLR_POOL_IDLE_SLEEP = 16 keeps an idle probe wave's back-off at s_sleep 16; default 64)
-		static const long is_env = [] {
-			const char *v = getenv("POLR_POOL_IDLE_SLEEP");
-			return v ? atol(v) : 0l;
-		}();
-		hr->idle_sleep = is_env == 16 ? 16u : 64u;
-	}
+	// (the size up to which a round is latency-critical)
+	hr->hi_tuples = ctx->tuning.hi_tuples_p1 ? std::min<uint32_t>(ctx->tuning.hi_tuples_p1 - 1u, POLR_POOL_HI_TUPLES)
+	                                         : POLR_POOL_HI_TUPLES;
+	hr->idle_sleep = ctx->tuning.idle_sleep == 16 ? 16u : 64u; // (an idle probe wave's longest back-off)
+	// watchdog: ticks of the 100 MHz wall clock (default 4 s: a wait this long is a lost run)
+	hr->timeout_ticks = ctx->tuning.watchdog_us ? (unsigned long long)ctx->tuning.watchdog_us * 100ull : POLR_RES_TIMEOUT_TICKS;
 	hr->routers_done = 0;
 	hr->abort = 0;
-	hr->host_words = nullptr;
+	// the rings belong to the multiplexer that leads the run: a run that is given up says so in ITS host words too,
+	// whichever router saw the watchdog fire (the leader's own router may have finished long before)
+	hr->host_words = m0->progress_dev;
 	for (uint32_t i = 0; i < n; i++) {
 		polr_mpx *m = ms[i];
+		m->leader = m0;
 		ex[i].mpx = m->dev;
 		ex[i].sync = m->sync_dev;
 		ex[i].counts = m->counts_dev;
@@ -779,7 +758,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hipError_t e =
 	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
 	                                        (PoolRun *)m0->execs_dev)
-	         : polr_launch_pool_kernel(dp.W, dp.k, n_blocks, wpb, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
+	         : polr_launch_pool_kernel(dp.W, dp.k, n_blocks, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
 	                                   (PoolRun *)m0->execs_dev, dout, dp.ext != 0);
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel launch failed: %s", hipGetErrorString(e));
@@ -918,6 +897,9 @@ int polr_mpx_finish(polr_mpx *m, void *stream, polr_mpx_stats *stats) {
 	if (((volatile uint32_t *)m->done_host)[2]) {
 		((volatile uint32_t *)m->done_host)[2] = 0;
 		m->pool_dirty = true;
+		if (m->leader) {
+			m->leader->pool_dirty = true; // (the rings of the run belong to its first multiplexer)
+		}
 		POLR_FAIL(ctx, POLR_E_HIP, "run timed out waiting for its probe waves (results incomplete)");
 	}
 	if (m->timing) {
@@ -969,8 +951,11 @@ int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
 			timed_out = true;
 		}
 		if (timed_out) {
-			ms[0]->pool_dirty = true; // (the multiplexer that leads the run owns its rings)
+			ms[0]->pool_dirty = true;
 			m->pool_dirty = true;
+			if (m->leader) {
+				m->leader->pool_dirty = true; // (the multiplexer that led the run owns its rings)
+			}
 		}
 	}
 	if (timed_out) {

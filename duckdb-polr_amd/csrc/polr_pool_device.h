@@ -116,7 +116,9 @@ struct PoolRun {
 	                                        // every ring has waves that serve it
 	uint32_t routers_done;                  // device: routers that have finished
 	uint32_t abort;                         // device: a watchdog fired
-	volatile uint32_t *host_words;          // pinned: [2] = 1 when the run was given up
+	volatile uint32_t *host_words;          // pinned words of the run's FIRST multiplexer (it owns the rings): [2] = 1 when
+	                                        // the run was given up, whichever router saw it
+	unsigned long long timeout_ticks;       // watchdog: longest wait, ticks of the 100 MHz wall clock
 	uint32_t worker_waves[POLR_POOL_RINGS]; // probe waves that poll ring r (EXIT entries to publish); read in place
 };
 
@@ -292,8 +294,8 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 // read its entry (being written by the router that reserved it)
 __device__ __forceinline__ bool polr_pool_try_claim(POLR_GLOBAL unsigned long long *head, POLR_GLOBAL unsigned long long *tail,
                                                     POLR_GLOBAL PoolEntry *entries, uint32_t cap, uint32_t wave_in_ring,
-                                                    uint32_t lottery, unsigned long long &g0, unsigned long long &g1,
-                                                    uint32_t &tag) {
+                                                    uint32_t lottery, unsigned long long timeout_ticks,
+                                                    unsigned long long &g0, unsigned long long &g1, uint32_t &tag) {
 	const unsigned long long hh = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const unsigned long long ht = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	if (hh >= ht || (((uint32_t)hh ^ wave_in_ring) & (lottery - 1u)) != 0) {
@@ -310,7 +312,7 @@ __device__ __forceinline__ bool polr_pool_try_claim(POLR_GLOBAL unsigned long lo
 	while (true) {
 		g0 = __hip_atomic_load(&e->g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		g1 = __hip_atomic_load(&e->g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) || wall_clock64() - t1 > POLR_RES_TIMEOUT_TICKS) {
+		if (((uint32_t)(g0 >> 48) == tag && (uint32_t)(g1 >> 48) == tag) || wall_clock64() - t1 > timeout_ticks) {
 			break;
 		}
 		__builtin_amdgcn_s_sleep(1);
@@ -327,11 +329,13 @@ struct PoolPoller {
 	POLR_GLOBAL PoolEntry *hi_q, *mid_q, *lo_q;
 	uint32_t lo_cap, hi_cap, wave_in_ring, lottery, idle_sleep;
 	unsigned long long lo_ticket, mid_ticket; // ~0ull: none
+	unsigned long long timeout_ticks;
 };
 
 __device__ __forceinline__ void polr_pool_poller_init(PoolPoller &pp, PoolRun *run_generic, PoolSync *sync_generic,
                                                       uint32_t ring, uint32_t lo_cap, uint32_t hi_cap,
-                                                      uint32_t wave_in_ring, uint32_t lottery, uint32_t idle_sleep) {
+                                                      uint32_t wave_in_ring, uint32_t lottery, uint32_t idle_sleep,
+                                                      unsigned long long timeout_ticks) {
 	pp.run = as_global(run_generic);
 	pp.ctl = as_global(&sync_generic->ctl[ring]);
 	pp.hi_q = as_global(polr_pool_hi(sync_generic, ring, lo_cap, hi_cap));
@@ -342,6 +346,7 @@ __device__ __forceinline__ void polr_pool_poller_init(PoolPoller &pp, PoolRun *r
 	pp.wave_in_ring = wave_in_ring;
 	pp.lottery = lottery;
 	pp.idle_sleep = idle_sleep;
+	pp.timeout_ticks = timeout_ticks;
 	pp.lo_ticket = pp.mid_ticket = ~0ull;
 }
 
@@ -355,8 +360,8 @@ __device__ __forceinline__ uint32_t polr_pool_poll(PoolPoller &pp, PoolUnit &u, 
 	uint32_t tag = 0, got = 0;
 	if (lane == 0) {
 		// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
-		got = polr_pool_try_claim(&pp.ctl->hi_head, &pp.ctl->hi_tail, pp.hi_q, pp.hi_cap, pp.wave_in_ring, pp.lottery, g0, g1,
-		                          tag)
+		got = polr_pool_try_claim(&pp.ctl->hi_head, &pp.ctl->hi_tail, pp.hi_q, pp.hi_cap, pp.wave_in_ring, pp.lottery,
+		                          pp.timeout_ticks, g0, g1, tag)
 		          ? 1u
 		          : 0u;
 		if (!got) {
@@ -623,9 +628,9 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			uint32_t spins = 0;
 			while (polr_pool_arrived(x.sync, front_slot, lane) != want) {
 				__builtin_amdgcn_s_sleep(1);
-				if ((++spins & 63u) == 0) {
+				if ((++spins & 7u) == 0) { // (every spin is a round trip to the arrival counters: a look every ~10 us)
 					uint32_t ab = __hip_atomic_load(&run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (ab || wall_clock64() - t0 > POLR_RES_TIMEOUT_TICKS) {
+					if (ab || wall_clock64() - t0 > rh.timeout_ticks) {
 						failed = true; // a probe wave is missing
 						break;
 					}

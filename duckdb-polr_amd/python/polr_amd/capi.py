@@ -34,6 +34,7 @@ EXPORTS = [
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_ranges", "polr_mpx_run_resident_morsels",
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
+    "polr_ctx_set_pool_tuning",
 ]
 
 
@@ -45,6 +46,13 @@ class PolrError(RuntimeError):
 
 class Col(C.Structure):
     _fields_ = [("data", C.c_void_p), ("valid", C.c_void_p), ("width", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class PoolTuning(C.Structure):
+    """polr_pool_tuning: 0 = the library's default"""
+    _fields_ = [("device_share", C.c_uint32), ("units_x", C.c_uint32), ("hi_unit", C.c_uint32),
+                ("hi_lottery", C.c_uint32), ("hi_tuples_p1", C.c_uint32), ("idle_sleep", C.c_uint32),
+                ("watchdog_us", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class JoinDesc(C.Structure):
@@ -125,6 +133,7 @@ def load():
     L.polr_last_error.argtypes = [vp]
     L.polr_last_error.restype = C.c_char_p
     L.polr_ctx_sync.argtypes = [vp, vp]
+    L.polr_ctx_set_pool_tuning.argtypes = [vp, C.POINTER(PoolTuning)]
     L.polr_ht_upload_rows.argtypes = [vp, vp, u64, u32, vp, vp, vp, u32, u32, P(vp)]
     L.polr_ht_upload_columns.argtypes = [vp, P(Col), u32, P(Col), u32, u64, P(vp)]
     L.polr_ht_finalize_hash.argtypes = [vp, vp]
@@ -221,6 +230,16 @@ class Context:
 
     def sync(self, stream=None):
         self.check(self.L.polr_ctx_sync(self.h, stream))
+
+    def set_pool_tuning(self, **kw):
+        """polr_ctx_set_pool_tuning; no arguments = every default.  hi_tuples=N is passed as hi_tuples_p1 = N + 1"""
+        if not kw:
+            self.check(self.L.polr_ctx_set_pool_tuning(self.h, None))
+            return
+        if "hi_tuples" in kw:
+            kw["hi_tuples_p1"] = int(kw.pop("hi_tuples")) + 1
+        t = PoolTuning(**{k: int(v) for k, v in kw.items()})
+        self.check(self.L.polr_ctx_set_pool_tuning(self.h, C.byref(t)))
 
     def close(self):
         if self.h:

@@ -83,6 +83,21 @@ int polr_ctx_create(int device_id, polr_ctx **out);
 void polr_ctx_destroy(polr_ctx *ctx);
 const char *polr_last_error(const polr_ctx *ctx);
 int polr_ctx_sync(polr_ctx *ctx, void *stream);
+/* Tuning of the pool launch (polr_mpx_run_resident*): how a context's runs cut rounds into units and how its probe
+ * waves poll.  A field left 0 keeps the library's default; NULL restores every default.  Results never depend on any
+ * of these (only speed does), except watchdog_us, which bounds how long a router waits for its probe waves before the
+ * run is given up with POLR_E_HIP.  Takes effect with the next run of the context. */
+typedef struct polr_pool_tuning {
+	uint32_t device_share; /* size every run's grid for 1/device_share of the device (1..16); 0: as the run's flags say */
+	uint32_t units_x;      /* a big round is cut into about units_x x probe waves / routing executors units (1..4; default 4) */
+	uint32_t hi_unit;      /* tuples per unit of a small round: 64..1024, a multiple of 64 (default: 1024 flat, 256 generic) */
+	uint32_t hi_lottery;   /* power of two: wave w of a ring tries for hi ticket t only if w % lottery == t % lottery */
+	uint32_t hi_tuples_p1; /* 1 + the size up to which a round counts as small (default 4096); 0: default */
+	uint32_t idle_sleep;   /* 16: an idle probe wave's back-off stays at s_sleep 16 (default 64) */
+	uint32_t watchdog_us;  /* microseconds; default 4 000 000 */
+	uint32_t reserved;     /* 0 */
+} polr_pool_tuning;
+int polr_ctx_set_pool_tuning(polr_ctx *ctx, const polr_pool_tuning *tuning);
 
 /* ---------------------------------------------------------------------------------------------
  * Build sides.  Replaces what JoinHashTable::Finalize leaves in host memory

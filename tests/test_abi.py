@@ -46,3 +46,17 @@ def test_product_never_imports_oracle():
                 if re.search(r"polr_oracle|oracle/|import oracle|from oracle", t):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_library_reads_no_tuning_from_the_environment():
+    """pool tuning travels through polr_ctx_set_pool_tuning (include/polr_hip.h); the device library has no getenv"""
+    pkg = os.path.join(common.ROOT, "duckdb-polr_amd", "csrc")
+    bad = []
+    for f in os.listdir(pkg):
+        if f.endswith((".hip", ".h")):
+            # (the one environment variable the library knows switches a debugging trace on: POLR_DEBUG_HIP_ERRORS)
+            bad += [(f, v) for v in re.findall(r'getenv\("([^"]*)"\)', open(os.path.join(pkg, f)).read())
+                    if not v.startswith("POLR_DEBUG_")]
+    assert not bad, bad
+    lib = capi.load()
+    assert lib.polr_ctx_set_pool_tuning(None, None) == capi.E_INVALID

@@ -37,3 +37,59 @@ def test_committed_bench_line_has_the_contract_shape():
     assert d["count_star_matches_reference"] is True
     for sub in d.get("sub_records", []):
         assert {"value", "ms_per_step", "roofline", "config"} <= set(sub)
+
+
+_RANK_SCRIPT = r"""
+import json, os, sys
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import torch
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "sum": float(t[0]), "argv": sys.argv[1:],
+                      "ranks_started": int(os.environ["POLR_RANKS_STARTED"])}))
+else:
+    print("noise from rank %d" % rank)
+dist.destroy_process_group()
+sys.exit(int(os.environ.get("FAIL_RANK", "-1")) == rank)
+"""
+
+
+def test_bench_starts_its_own_ranks(tmp_path, capsys):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes with the launcher's environment, a
+    rendezvous on 127.0.0.1, ONE line relayed (rank 0's), non-zero when any rank fails -- two gloo ranks on the CPU"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(common.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rc = bench.spawn_ranks(2, argv=["--gpus", "2", "--steps", "3"], script=str(script))
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1
+    d = json.loads(out[0])
+    assert d == {"n_gpus": 2, "sum": 3.0, "argv": ["--gpus", "2", "--steps", "3"], "ranks_started": 2}
+    rc = bench.spawn_ranks(2, argv=[], script=str(script), extra_env={"FAIL_RANK": "1"})
+    capsys.readouterr()
+    assert rc != 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """no launcher and fewer visible GPUs than --gpus: a clear error, never a silent one-rank measurement"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "POLR_SHARE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr and not p.stdout.strip()
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    p = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "must agree" in p.stderr

@@ -273,3 +273,36 @@ def test_round_counter_wraps(gpu_ctx):
     assert st["num_intermediates"] == ref["num_intermediates"]
     mpx.close()
     pipe.close()
+
+
+def test_a_given_up_run_leaves_the_rings_usable(gpu_ctx):
+    """the device-side watchdog (polr_pool_tuning.watchdog_us) gives a run up: polr_mpx_finish_many reports POLR_E_HIP, and
+    the next run on the same rings -- owned by the run's FIRST multiplexer, whose own router had finished long before the
+    other executor's watchdog fired -- starts from re-initialised rings and is correct"""
+    wl = workloads.star_skew(n_fact=12_000_000)
+    k = len(wl["joins"])
+    paths = workloads.default_paths(k, "each_last_once")
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    n = len(pcols[0])
+    joins = capi.build_joins(gpu_ctx, wl)
+    pipe = capi.Pipeline(gpu_ctx, pcols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    ms = [capi.DeviceMultiplexer(pipe, "default_path") for _ in range(2)]
+    ranges = [(0, 1), (1, n_chunks)]  # executor 0 (the leader) routes one chunk and is done
+    try:
+        gpu_ctx.set_pool_tuning(watchdog_us=1)
+        capi.run_resident(ms, ranges, reset=True, finish=True)
+        with pytest.raises(capi.PolrError) as e:
+            capi.finish_many(ms)
+        assert e.value.code == capi.E_HIP and "timed out" in str(e.value)
+    finally:
+        gpu_ctx.set_pool_tuning()
+    ref = orc.run_pipeline(pcols, ojoins, paths, routing="default_path", caching=False, collect_output=False)
+    for _ in range(2):
+        capi.run_resident(ms, ranges, reset=True, finish=True)
+        sts = capi.finish_many(ms)
+        assert sum(st["num_intermediates"] for st in sts) == ref["num_intermediates"]
+        assert sum(sum(st["input_tuple_count_per_path"]) for st in sts) == n
+    for m in ms:
+        m.close()
+    pipe.close()
