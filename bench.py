@@ -491,11 +491,13 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         n_waves = 256 * 16
         tl = torch.zeros(n_waves * cap_tl * 4, dtype=torch.int64, device=dev)
         kk = 2 if k <= 2 else 4 if k <= 4 else 6 if k <= 6 else 8
-        fn = getattr(ctx.L, "polr_diag_timeline_set_k%d" % kk)
+        # (the flat pipeline's kernels are built per stage count; the generic pipeline's kernel is one, in two builds)
+        sfx = ("k%d" % kk) if pipe.launch_info(False).get("flat") else "g"
+        fn = getattr(ctx.L, "polr_diag_timeline_set_%s" % sfx)
         fn.argtypes = [C.c_void_p, C.c_uint32]
         if fn(tl.data_ptr(), cap_tl) != 0:
             raise SystemExit("polr_diag_timeline_set failed")
-        ph = getattr(ctx.L, "polr_diag_router_k%d" % kk)
+        ph = getattr(ctx.L, "polr_diag_router_%s" % sfx)
         ph.argtypes = [C.c_void_p, C.c_int]
         pbuf = (C.c_uint64 * 16)()
         ph(pbuf, 1)
@@ -766,7 +768,11 @@ def run_job_full(args, env, steps, warmup, with_cpu):
             capi.run_resident(c["mpxs"], c["ranges"], reset=True, finish=True)
         if fetch:
             for c in cases:
-                stats[c["name"]] = capi.finish_many(c["mpxs"])
+                try:
+                    stats[c["name"]] = capi.finish_many(c["mpxs"])
+                except capi.PolrError as e:
+                    raise SystemExit("job_full: pipeline %s (%d joins: %s; %d probe tuples; join orders %s): %s" % (
+                        c["name"], c["k"], [j["name"] for j in c["wl"]["joins"]], c["n_tuples"], c["paths"].tolist(), e))
 
     for _ in range(warmup):
         t_w = time.time()
@@ -793,10 +799,12 @@ def run_job_full(args, env, steps, warmup, with_cpu):
             step(i == steps - 1)
         torch.cuda.synchronize()
         for c in cases:
+            c["kernel_ms"] = 0.0
             for m in c["mpxs"]:
                 ms_e, n_e = m.kernel_time()
                 kernel_ms += ms_e
                 launches += n_e
+                c["kernel_ms"] += ms_e / steps
                 m.enable_timing(False)
     my_tuples = sum(c["n_tuples"] for c in cases)
     value, dt_max, total_tuples = pdist.whole_job_throughput(dist, torch, dev, world, my_tuples, dt, steps)
@@ -848,8 +856,21 @@ def run_job_full(args, env, steps, warmup, with_cpu):
                                  "its queries exist as shapes only)" % (cap, min(4, len(cases)))}
             except Exception as e:
                 cpu = {"value": None, "error": str(e)[:300]}
+        # which pipelines carry the pass: the ten longest, with what their joins produced (all join orders together)
+        slowest = []
+        for c in sorted(cases, key=lambda c_: -c_.get("kernel_ms", 0.0))[:10]:
+            P, k = len(c["paths"]), c["k"]
+            so = [sum(st["stage_out"][p][j] for st in stats[c["name"]] for p in range(P)) for j in range(k)]
+            tpp = [sum(st["input_tuple_count_per_path"][p] for st in stats[c["name"]]) for p in range(P)]
+            slowest.append({"query": c["name"], "kernel_ms": round(c.get("kernel_ms", 0.0), 3), "probe_tuples": c["n_tuples"],
+                            "joins": [j["name"] for j in c["wl"]["joins"]],
+                            "build_rows": [len(j["keys"][0]) for j in c["wl"]["joins"]],
+                            "tables": ["perfect" if ji["perfect"] else "hash" for ji in c["ji"]],
+                            "produced_by_position": so, "tuples_per_join_order": tpp,
+                            "flat": int(c["pipe"].launch_info(False).get("flat", 0))})
         rec = {"metric": "probe-tuples/s", "value": round(value, 1), "unit": "tuples/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": round(dt_max / steps * 1e3, 4), "higher_is_better": True,
+               "slowest_pipelines": slowest,
                "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": "job_full: the 113 JOB-shaped pipelines (IMDB cardinalities x%.3g), %d of them on "
                                       "this rank, %d probe tuples per pass on this rank; whole queries round-robin over "

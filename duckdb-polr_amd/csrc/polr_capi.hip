@@ -1393,6 +1393,17 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 			}
 		}
 		c.W = w;
+		// multiplicities (polr_gen_device.h): worth a tuple slot when some join's matches can be folded into them -- its
+		// build key may repeat, nobody reads its build rows downstream, it has no non-equality condition
+		c.mult = 0;
+		for (uint32_t j = 0; j < k; j++) {
+			const polr_ht *ht = joins[j].ht;
+			const bool repeats = !(ht->kind == KIND_PERFECT || ht->kind == KIND_S8 || ht->max_run <= 1);
+			if (repeats && c.slot_of_join[j] < 0 && joins[j].n_preds == 0) {
+				c.mult = 1;
+			}
+		}
+		p->host_mat.mult = 0;
 		std::vector<StageDesc> sd_mat, sd_count;
 		std::vector<StageExt> sd_ext;
 		build_stage_descs(p, p->host_mat, sd_mat, sd_ext);

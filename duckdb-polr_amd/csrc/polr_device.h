@@ -159,7 +159,8 @@ struct DevPipeline {
 	uint32_t W;             // slots carried per tuple: 1 (probe row) + carried build ids
 	uint32_t materialize;   // 1: all build ids carried, slot 1+j = join j
 	uint32_t ext;           // some stage has an extension record (packed composite key, non-equality conditions): POLR_EXT kernels
-	uint32_t ext_pad;
+	uint32_t mult;          // 1 (counting variant, pool launch): tuples carry a multiplicity in one more slot behind the W id slots
+	                        // -- some join's matches are folded into it instead of being handed on one by one (polr_gen_device.h)
 	int32_t slot_of_join[POLR_KMAX]; // slot index holding join j's build id, or -1
 	const DevCol *probe_cols;
 	const uint32_t *sel;    // nullptr = identity

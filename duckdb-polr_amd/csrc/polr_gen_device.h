@@ -27,6 +27,13 @@
 //     like the reference's in_process_joins stack (polar_pipeline_executor.cpp:296-420): LDS use is bounded for any
 //     fan-out, and the only per-wave scratch is one 2 KB area for the prefix sums of the step in progress.
 //   * a counting sink never expands the last join: its run lengths are summed.
+//   * MULTIPLICITIES (counting runs): a join whose build rows nobody reads downstream -- its build id is not a later
+//     join's key source, it has no non-equality condition, nothing is materialised -- does not have to hand its matches
+//     on one by one: the tuple goes on ONCE with its multiplicity multiplied by the run length, and every counter adds
+//     multiplicities instead of ones.  Counts (per-join intermediates, COUNT(*)) are exactly those of the expanded
+//     stream -- the reference's NextInnerJoin would have produced run-length copies that are indistinguishable to every
+//     later join (join_hashtable.cpp:531-565) -- at none of its work; a skewed build key (JOB's movie_keyword /
+//     movie_info runs of thousands of rows) no longer leaves one wave expanding millions of pairs alone.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,7 +48,9 @@
 
 #define POLR_CONST __attribute__((address_space(4)))
 
+#ifndef GEN_F
 #define GEN_F 4                 // candidates per lane and step
+#endif
 #define GEN_STEP (64 * GEN_F)   // candidates per step
 #define GEN_SCRATCH_DWORDS (2 * GEN_STEP) // run starts, inclusive prefix of run lengths
 #define GEN_NO_CHUNK 0xFFFFFFFFu
@@ -51,6 +60,13 @@ __device__ __forceinline__ uint32_t gen_uni(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t gen_rank(uint64_t m) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+__device__ __forceinline__ uint64_t gen_wave_sum64(uint64_t v) { // the same sum in every lane
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		v += __shfl_xor(v, d, 64);
+	}
+	return v;
 }
 __device__ __forceinline__ uint32_t gen_lane_get(uint32_t v, uint32_t lane_uniform) {
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane_uniform);
@@ -148,10 +164,11 @@ struct GenCtx {
 	const POLR_CONST StageDesc *stages; // the k descriptors of the current join order
 	// lane p: state of stage p
 	uint32_t v_qsize;  // entries waiting in the queue that feeds stage p
-	uint32_t v_cnt;    // tuples stage p has produced in this unit
+	uint32_t v_cnt_lo, v_cnt_hi; // tuples stage p has produced in this unit (64 bits: multiplicities)
 	uint32_t v_gstart; // pending run of stage p: next position in rowids[] ...
 	uint32_t v_grem;   // ... and how many build rows of it are still to be emitted (0: none pending)
 	uint64_t in_pos, in_end;
+	bool mult; // tuple slot W - 1 carries the tuple's multiplicity (counting runs of pipelines with foldable joins)
 	// output (row ids)
 	DevOut out;
 	bool emit, overflow;
@@ -456,9 +473,9 @@ __device__ __forceinline__ void gen_out_write(GenCtx<W> &c, const GenTuple<W> &t
 }
 
 // one sub-batch of (tuple, build id) pairs leaves stage `pos`: conditions, counter, next queue or output.
-// qs_next: fill of the next queue (updated); returns the number of pairs that passed
+// qs_next: fill of the next queue (updated); returns the number of tuples that passed (the sum of their multiplicities)
 template <int W>
-__device__ __forceinline__ uint32_t gen_emit(GenCtx<W> &c, const GenStage &s, uint32_t pos, bool last, GenTuple<W> t, uint32_t id,
+__device__ __forceinline__ uint64_t gen_emit(GenCtx<W> &c, const GenStage &s, uint32_t pos, bool last, GenTuple<W> t, uint32_t id,
                                              bool valid, uint32_t &qs_next) {
 #if POLR_EXT
 	if (s.xflags >> 8) {
@@ -484,6 +501,9 @@ __device__ __forceinline__ uint32_t gen_emit(GenCtx<W> &c, const GenStage &s, ui
 			}
 		}
 		qs_next += n;
+	}
+	if (c.mult) {
+		return gen_wave_sum64(valid ? (uint64_t)t.s[W - 1] : 0ull);
 	}
 	return n;
 }
@@ -512,6 +532,9 @@ __device__ __forceinline__ GenTuple<W> gen_candidate(const GenCtx<W> &c, uint32_
 		if (pos == 0) {
 			const uint64_t tp = c.in_pos + ci;
 			t.s[0] = c.sel ? c.sel[tp] : (uint32_t)tp;
+			if (c.mult) {
+				t.s[W - 1] = 1u;
+			}
 		} else {
 			const POLR_LDS uint32_t *qq = c.q + (size_t)(pos - 1) * W * c.qcap;
 			const uint32_t qi = qs - 1u - ci;
@@ -533,7 +556,7 @@ __device__ __forceinline__ void gen_step(GenCtx<W> &c, const uint32_t pos) {
 	uint32_t qs_next = last ? 0u : gen_lane_get(c.v_qsize, pos + 1);
 	const uint32_t room = last ? 0xFFFFFFFFu : c.qcap - qs_next;
 	const bool need_id = s.out_slot >= 0 || (s.xflags >> 8) != 0;
-	uint32_t produced = 0;
+	uint64_t produced = 0;
 	const uint32_t grem = gen_lane_get(c.v_grem, pos);
 	if (grem) {
 		// the pending run of this stage: candidate 0 (still at the source front / the queue top) x its next build rows
@@ -603,26 +626,63 @@ __device__ __forceinline__ void gen_step(GenCtx<W> &c, const uint32_t pos) {
 			hits += (uint32_t)__popcll(__ballot(count[i] != 0u));
 		}
 		multi = __ballot(multi) != 0ull;
+		if (multi && c.mult && !need_id) {
+			// nobody downstream reads this join's build rows: a run of r rows multiplies the tuple's multiplicity by r
+			// instead of making r copies (unless a product leaves 32 bits: then this step expands, copies keep theirs)
+			bool wide = false;
+#pragma unroll
+			for (int i = 0; i < GEN_F; i++) {
+				wide = wide || ((uint64_t)t[i].s[W - 1] * (uint64_t)count[i]) > 0xFFFFFFFFull;
+			}
+			if (__ballot(wide) == 0ull) {
+#pragma unroll
+				for (int i = 0; i < GEN_F; i++) {
+					if (count[i]) {
+						t[i].s[W - 1] *= count[i];
+						count[i] = 1u;
+					}
+				}
+				multi = false;
+			}
+		}
 		uint32_t consumed = n;
-		if (!multi && hits <= room) {
-			// at most one build row per candidate, and everything fits: compact and push
+		if (!multi) {
+			// at most one tuple goes on per candidate (one build row, or a run folded into the multiplicity): compact and
+			// push, straight from the registers.  More matches than the next queue takes: only the longest prefix of
+			// candidates whose matches fit is consumed, the others stay where they are
+			bool keep[GEN_F];
+#pragma unroll
+			for (int i = 0; i < GEN_F; i++) {
+				keep[i] = act[i];
+			}
+			if (hits > room) {
+				uint32_t carry = 0;
+				consumed = 0;
+#pragma unroll
+				for (int i = 0; i < GEN_F; i++) {
+					const uint32_t incl = carry + gen_inclusive_scan(count[i] != 0u ? 1u : 0u, c.lane);
+					carry = gen_lane_get(incl, 63);
+					keep[i] = act[i] && incl <= room;
+					consumed += (uint32_t)__popcll(__ballot(keep[i]));
+				}
+			}
 			uint32_t id[GEN_F];
 #pragma unroll
 			for (int i = 0; i < GEN_F; i++) {
 				id[i] = start[i];
 				if (s.kind == KIND_S16) {
-					id[i] = (count[i] && need_id) ? s.rowids[start[i]] : 0u;
+					id[i] = (count[i] && keep[i] && need_id) ? s.rowids[start[i]] : 0u;
 				}
 			}
 #pragma unroll
 			for (int i = 0; i < GEN_F; i++) {
 				if (64u * i < n) {
-					produced += gen_emit<W>(c, s, pos, last, t[i], id[i], count[i] != 0u, qs_next);
+					produced += gen_emit<W>(c, s, pos, last, t[i], id[i], count[i] != 0u && keep[i], qs_next);
 				}
 			}
 		} else {
-			// runs of build rows (or more matches than the next queue takes): inclusive prefix of the run lengths over
-			// the candidates, in consumption order
+			// runs of build rows whose rows are needed one by one (no fold happened in this step: the tuples are read
+			// back from where they wait): inclusive prefix of the run lengths over the candidates, in consumption order
 			POLR_LDS uint32_t *sc_start = c.scratch;
 			POLR_LDS uint32_t *sc_pref = c.scratch + GEN_STEP;
 			uint32_t carry = 0;
@@ -636,7 +696,17 @@ __device__ __forceinline__ void gen_step(GenCtx<W> &c, const uint32_t pos) {
 			}
 			const uint32_t total = carry;
 			if (last && !c.emit && (s.xflags >> 8) == 0) {
-				produced = total; // a counting sink: the run lengths are all it needs
+				// a counting sink: the run lengths are all it needs
+				if (c.mult) {
+					uint64_t w = 0;
+#pragma unroll
+					for (int i = 0; i < GEN_F; i++) {
+						w += (uint64_t)t[i].s[W - 1] * (uint64_t)count[i];
+					}
+					produced = gen_wave_sum64(w);
+				} else {
+					produced = total;
+				}
 			} else {
 				uint32_t m = n, total_m = total;
 				if (total > room) {
@@ -702,7 +772,9 @@ __device__ __forceinline__ void gen_step(GenCtx<W> &c, const uint32_t pos) {
 	if (!last) {
 		gen_lane_set(c.v_qsize, pos + 1, qs_next);
 	}
-	gen_lane_set(c.v_cnt, pos, gen_lane_get(c.v_cnt, pos) + produced);
+	const uint64_t so_far = (((uint64_t)gen_lane_get(c.v_cnt_hi, pos) << 32) | gen_lane_get(c.v_cnt_lo, pos)) + produced;
+	gen_lane_set(c.v_cnt_lo, pos, (uint32_t)so_far);
+	gen_lane_set(c.v_cnt_hi, pos, (uint32_t)(so_far >> 32));
 }
 
 // ---- scheduler: one unit [in_pos, in_end), until nothing is left anywhere (a unit leaves nothing behind: its counters

@@ -293,18 +293,19 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
 	const bool mat = materialize != 0;
 	const DevPipeline &dp = mat ? p->host_mat : p->host_count;
 	const bool flat = !mat && dp.flat != 0;
-	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, dp.W);
+	const uint32_t wq = dp.W + (dp.mult ? 1u : 0u); // slots per queued tuple in the pool launch: ids (+ multiplicity)
+	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, wq);
 	memset(info, 0, sizeof(*info));
 	info->waves_per_workgroup = wpb;
-	const int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, dp.ext != 0));
+	const int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
 	if (occ < 1) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
 	}
 	info->workgroups_per_cu = (uint32_t)std::max(0, std::min(occ, 8));
 	info->lds_bytes_per_workgroup = (uint32_t)(flat ? polr_pool_flat_lds_bytes(dp.k, wpb, dp.lds_table_dwords)
-	                                                : polr_pool_lds_bytes(dp.k, dp.W));
+	                                                : polr_pool_lds_bytes(dp.k, wq));
 	info->compiled_stages = dp.k <= 2 ? 2 : (dp.k <= 4 ? 4 : (dp.k <= 6 ? 6 : 8));
-	info->tuple_slots = dp.W;
+	info->tuple_slots = flat ? dp.W : wq;
 	info->n_cus = (uint32_t)ctx->n_cus;
 	info->flat = flat ? 1u : 0u;
 	info->lds_tables = flat ? dp.n_lds_tables : 0u;
@@ -570,8 +571,9 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	const bool materialize = out != nullptr;
 	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
 	const bool flat = !materialize && dp.flat != 0;
-	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, dp.W);
-	int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, dp.W, dp.ext != 0));
+	const uint32_t wq = dp.W + (dp.mult ? 1u : 0u); // slots per queued tuple: ids (+ multiplicity)
+	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, wq);
+	int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
 	if (occ < 1) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "pool kernel does not fit on a CU (per-wave LDS queues: too many joins x carried ids)");
 	}
@@ -758,7 +760,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hipError_t e =
 	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
 	                                        (PoolRun *)m0->execs_dev)
-	         : polr_launch_pool_kernel(dp.W, dp.k, n_blocks, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
+	         : polr_launch_pool_kernel(wq, dp.k, n_blocks, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
 	                                   (PoolRun *)m0->execs_dev, dout, dp.ext != 0);
 	if (e != hipSuccess) {
 		POLR_FAIL(ctx, POLR_E_HIP, "pool kernel launch failed: %s", hipGetErrorString(e));

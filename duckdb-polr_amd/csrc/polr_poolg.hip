@@ -30,8 +30,8 @@ POOL_DIAG_ENTRY(polr_diag_router_g, polr_diag_timeline_set_g)
 #define POOLG_WAVES 8 // waves per workgroup, at most (fewer when the queues of 8 waves would not leave room for two workgroups per CU)
 
 // a probe wave reports a finished unit: its stage counters (returning atomics), then the arrival
-__device__ __forceinline__ void poolg_arrive(const ResidentExec *execs, const PoolUnit &u, uint32_t ring, uint32_t k, uint32_t &v_cnt,
-                                             uint32_t lane) {
+__device__ __forceinline__ void poolg_arrive(const ResidentExec *execs, const PoolUnit &u, uint32_t ring, uint32_t k, uint32_t &v_cnt_lo,
+                                             uint32_t &v_cnt_hi, uint32_t lane) {
 	const POLR_GLOBAL ResidentExec *xp = as_global(execs) + u.exec;
 	POLR_GLOBAL unsigned long long *bank = as_global((unsigned long long *)uni64((uint64_t)xp->counts)) +
 	                                       (size_t)u.slot * POLR_NSHARD * POLR_KMAX +
@@ -40,8 +40,9 @@ __device__ __forceinline__ void poolg_arrive(const ResidentExec *execs, const Po
 	// lane p adds stage p's counter (one instruction for all stages); the returned values are folded into the arrival's
 	// operand, so the arrival is issued after the adds have been performed
 	unsigned long long seen = 0;
-	if (lane < k && v_cnt) {
-		seen = __hip_atomic_fetch_add(&bank[lane], (unsigned long long)v_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long mine = ((unsigned long long)v_cnt_hi << 32) | v_cnt_lo;
+	if (lane < k && mine) {
+		seen = __hip_atomic_fetch_add(&bank[lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	seen >>= 63;
 	for (int d = 4; d > 0; d >>= 1) {
@@ -51,7 +52,7 @@ __device__ __forceinline__ void poolg_arrive(const ResidentExec *execs, const Po
 		__hip_atomic_fetch_add(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, 1ull + seen, __ATOMIC_RELAXED,
 		                       __HIP_MEMORY_SCOPE_AGENT);
 	}
-	v_cnt = 0;
+	v_cnt_lo = v_cnt_hi = 0;
 }
 
 // (EXT is part of the kernel's name: the two builds of this file are linked into one library)
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(64 * POOLG_WAVES, 4) void polr_pool_gen_kernel(cons
 	c.scratch = base;
 	c.q = base + GEN_SCRATCH_DWORDS;
 	c.sel = as_global(uniptr(pipe->sel));
-	c.v_qsize = c.v_cnt = c.v_gstart = c.v_grem = 0;
+	c.v_qsize = c.v_cnt_lo = c.v_cnt_hi = c.v_gstart = c.v_grem = 0;
+	c.mult = uni(pipe->mult) != 0;
 	c.in_pos = c.in_end = 0;
 	c.out = out;
 	c.emit = false;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(64 * POOLG_WAVES, 4) void polr_pool_gen_kernel(cons
 		c.in_end = (uint64_t)u.begin + u.count;
 		gen_run_unit<W>(c);
 		TL_RUN
-		poolg_arrive(execs, u, ring, k, c.v_cnt, c.lane);
+		poolg_arrive(execs, u, ring, k, c.v_cnt_lo, c.v_cnt_hi, c.lane);
 		TL_DONE(u)
 	}
 	if (c.cur_chunk != GEN_NO_CHUNK && c.lane == 0) {

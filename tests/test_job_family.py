@@ -86,3 +86,45 @@ def test_device_matches_oracle(gpu_ctx, name):
         assert st["num_intermediates"] == ref["num_intermediates"]
         mpx.close()
     pipe.close()
+
+
+@pytest.mark.gpu
+def test_pool_launch_and_path_kernel_agree_on_all_113(gpu_ctx):
+    """every join order of every one of the 113 pipelines through the POOL launch (generic pipeline of
+    polr_gen_device.h with multiplicity folding, or the flat pipeline) and through the per-round path kernel
+    (polr_probe_device.h): two independent implementations of RunPath; the tuples every join produces at every position
+    of every join order must be identical (what the multiplexer's reward is computed from), and COUNT(*) the same down
+    every join order"""
+    from polr_amd import capi
+    t = jf.Tables(scale=0.03)
+    checked = 0
+    for name in sorted(SHAPES):
+        wl = jf.workload(name, t, SHAPES[name])
+        pn = list(wl["probe"]["cols"].keys())
+        paths = phost.generate_join_orders("each_last_once", len(pn), [len(j["payload"]) for j in wl["joins"]],
+                                           wl["cond_left_index"], [len(j["keys"][0]) for j in wl["joins"]],
+                                           max_join_orders=8)[0]
+        joins = capi.build_joins(gpu_ctx, wl, auto=True)
+        cols = list(wl["probe"]["cols"].values())
+        pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, paths)
+        flt = wl["probe"].get("filter")
+        if flt:
+            n, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt])
+        else:
+            n, n_chunks = len(cols[0]), (len(cols[0]) + 1023) // 1024
+        k, P = len(wl["joins"]), len(paths)
+        want = pipe.probe_rounds([(0, n, p, 0) for p in range(P)])
+        mpx = capi.DeviceMultiplexer(pipe, "alternate", log_rounds=False)
+        if flt:
+            mpx.use_scan_chunks()
+        capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+        st = mpx.finish()
+        got = np.asarray([[st["stage_out"][p][j] for j in range(k)] for p in range(P)], dtype=np.uint64)
+        assert np.array_equal(got, want), name
+        assert len(set(int(x) for x in want[:, k - 1])) == 1, name  # COUNT(*) does not depend on the join order
+        checked += 1
+        mpx.close()
+        pipe.close()
+        for ht, _ in joins:
+            ht.close()
+    assert checked == 113
