@@ -37,13 +37,14 @@ struct JoinCondition {
 // ExtractInfoLinear polar_enumeration_algo.cpp:190-246): the scanned base table's cardinality
 // (DataTableInfo::cardinality, exact), whether the scan carries pushed-down table filters or sits under a FILTER
 // (`predicate`), and whether a UNIQUE / PRIMARY KEY constraint covers a scanned column (`unique`).  The host mirror has no
-// plan trees: the engine that owns them fills these in when it creates the operator.  nested = the build side is itself
-// a join tree (the reference recurses into it; not mirrored: SAMPLE throws).
+// plan trees: the engine that owns them fills these in when it creates the operator.  nested_join_order: the build side
+// is itself a join tree -- its source, then the build side of each of its joins, bottom up (CreateJoinOrderNodes recursing,
+// polar_enumeration_algo.cpp:248-287); such a node's own cardinality is that of its nested order (:401-409).
 struct JoinOrderNodeInfo {
 	idx_t base_table_card = 0;
 	bool predicate = false;
 	bool unique = false;
-	bool nested = false;
+	vector<JoinOrderNodeInfo> nested_join_order;
 };
 
 struct PerfectHashJoinStats {

@@ -2,11 +2,16 @@
 // (src/include/duckdb/parallel/polar_enumeration_algo.hpp:22-131, src/parallel/polar_enumeration_algo.cpp).
 // Setup only (once per pipeline, host side); the "bank of alternative probe orders" the multiplexer
 // routes over.  Path 0 is always the optimizer's original order.
+//
+// The class names and GenerateJoinOrders are the reference's (a mirror of its interface); everything behind them is
+// this repository's own: join sets are 64-bit masks, a join's prerequisites one mask (CanJoin = one AND), the
+// depth-first and breadth-first walks run off explicit work lists, and SelSampleEnumeration's DPsize keeps its best
+// plans in a flat table indexed by the join-subset mask.  What has to be the reference's is only what decides the
+// RESULT: the order in which candidates are visited and -- for SAMPLE -- the order in which random numbers are drawn.
 #pragma once
 
 #include <map>
 #include <random>
-#include <set>
 #include <unordered_map>
 
 #include "physical_hash_join.hpp"
@@ -17,13 +22,13 @@ namespace duckdb_polr {
 using JoinOrder = vector<idx_t>;                             // a permutation (or a prefix of one) of join indices
 using JoinList = vector<PhysicalHashJoin *>;                 // the multiplexed joins, original order
 using DependencyMap = std::unordered_map<idx_t, JoinOrder>;  // join -> joins whose build columns it is keyed by
+using JoinMask = uint64_t;                                   // a set of joins (bit j = join j) or of plan nodes
 
 // ---- how a min-card / uncertain / random enumerator picks among the joins that may come next ------------------
 class CandidateSelector {
 public:
 	virtual ~CandidateSelector() = default;
-	virtual idx_t SelectNextCandidate(const JoinOrder &candidates,
-	                                  const JoinList &joins_p) = 0;
+	virtual idx_t SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins_p) = 0;
 };
 
 class RandomCandidateSelector : public CandidateSelector {
@@ -42,7 +47,20 @@ public:
 class UncertainCardinalitySelector : public CandidateSelector {
 public:
 	idx_t SelectNextCandidate(const JoinOrder &candidates, const JoinList &joins) override;
-	std::unordered_map<idx_t, idx_t> uncertainties;
+
+private:
+	std::unordered_map<idx_t, idx_t> score_of; // level x estimated cardinality, computed once per join
+};
+
+// the prerequisites of every join as masks: join j may follow the set `placed` iff (needs[j] & ~placed) == 0
+struct Prerequisites {
+	explicit Prerequisites(idx_t n_joins, const DependencyMap &dependencies);
+	bool MayFollow(JoinMask placed, idx_t join) const {
+		return (needs[join] & ~placed) == 0;
+	}
+	vector<idx_t> Candidates(JoinMask placed) const; // the unplaced joins that may come next, ascending
+	idx_t n_joins;
+	vector<JoinMask> needs;
 };
 
 // ---- the enumerators (JoinEnumerator values of join_enumerator.hpp:15-25) --------------------------------------
@@ -50,9 +68,8 @@ public:
 class JoinEnumerationAlgo {
 public:
 	virtual ~JoinEnumerationAlgo() = default;
-	virtual void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs,
-	                                DependencyMap &dependencies,
-	                                const JoinList &joins, vector<JoinOrder> &join_orders);
+	virtual void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
+	                                vector<JoinOrder> &join_orders);
 	bool CanJoin(vector<idx_t> &r, idx_t s, DependencyMap &dependencies);
 	bool CanJoin(vector<idx_t> &r, vector<idx_t> &s, DependencyMap &dependencies); // ANY of s may follow r (:137-145)
 	static unique_ptr<JoinEnumerationAlgo> CreateEnumerationAlgo(ClientContext &context);
@@ -63,37 +80,40 @@ public:
 // DEFAULT enumerator (client_config.hpp:90): max_join_orders rounds of DPsize over the joins, each round with freshly
 // SAMPLED selectivities for the relations that carry a predicate, so that every round may crown a different order; the
 // bank = the original order + the distinct winners, in lexicographic order.  Randomness: std::mt19937(1337) through
-// std::uniform_real_distribution<double> -- the same libstdc++ classes here, hence the same stream.  Nodes are
-// identified by their position (0 = the pipeline's source, 1 + j = join j): the reference keys its maps by node
-// POINTERS into one contiguous vector, which order the same way.
+// std::uniform_real_distribution<double> -- the same libstdc++ classes here, hence the same stream.
+// Plan nodes are numbered: 0 = the pipeline's source, 1 + j = the build side of join j, and the nodes of a NESTED build
+// side (a build side that is itself a join tree: JoinOrderNodeInfo::nested_join_order) behind them, depth first.
 class SelSampleEnumeration : public JoinEnumerationAlgo {
 public:
-	using NodeSet = std::set<idx_t>;
-	using NodeSeq = vector<idx_t>;
+	using NodeSeq = vector<uint8_t>; // an ORDERED list of plan nodes (a plan prefix: source first)
 	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
 	                        vector<JoinOrder> &join_orders) override;
-	NodeSeq DpSize(const vector<JoinOrderNodeInfo> &nodes, DependencyMap &dependencies);
-	double CalculateCost(const NodeSeq &join_order);
 
 private:
-	const vector<JoinOrderNodeInfo> *nodes = nullptr;
-	std::map<NodeSeq, double> cost_map;
-	std::map<NodeSet, double> card_map;
-	std::map<NodeSet, NodeSeq> best_plans;
+	struct PlanNode {
+		double base_table_card;
+		bool predicate, unique;
+		vector<uint8_t> nested; // ids of the nodes of its nested join order, in that order
+	};
+	uint8_t AddNode(const JoinOrderNodeInfo &info);
+	JoinOrder OneRound(const Prerequisites &pre);            // DPsize with this round's samples: the winning order
+	double PlanCost(const NodeSeq &plan);                    // sum of the intermediate cardinalities of `plan`
+	double SampleSelectivity(bool index_from_sample);
+	static JoinMask MaskOf(const NodeSeq &nodes);
+	vector<PlanNode> nodes;
+	// memo of one round
+	std::map<NodeSeq, double> cost_of;               // by ordered prefix
+	std::unordered_map<JoinMask, double> card_of;    // by node set
 	std::mt19937 rng = std::mt19937(1337);
 	std::uniform_real_distribution<double> dist;
-	const vector<double> SEL_STEPS = {0.0001, 0.001, 0.01, 0.1, 0.2, 0.4, 0.8};
 };
 
 class DFSEnumeration : public JoinEnumerationAlgo {
 public:
 	explicit DFSEnumeration(unique_ptr<CandidateSelector> selector_p) : selector(std::move(selector_p)) {
 	}
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
-	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
-	void GeneratePathsRecursive(const JoinList &joins,
-	                            DependencyMap &join_prerequisites,
-	                            vector<vector<idx_t>> &result, vector<idx_t> join_seq, vector<idx_t> joins_left);
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
+	                        vector<JoinOrder> &join_orders) override;
 	const unique_ptr<CandidateSelector> selector;
 };
 
@@ -101,23 +121,21 @@ class BFSEnumeration : public JoinEnumerationAlgo {
 public:
 	explicit BFSEnumeration(unique_ptr<CandidateSelector> selector_p) : selector(std::move(selector_p)) {
 	}
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
-	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
-	vector<idx_t> FindJoinCandidates(idx_t join_count, vector<idx_t> &predecessors,
-	                                 DependencyMap &dependencies);
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
+	                        vector<JoinOrder> &join_orders) override;
 	const unique_ptr<CandidateSelector> selector;
 };
 
 class EachLastOnceEnumeration : public JoinEnumerationAlgo {
 public:
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
-	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
+	                        vector<JoinOrder> &join_orders) override;
 };
 
 class EachFirstOnceEnumeration : public JoinEnumerationAlgo {
 public:
-	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies,
-	                        const JoinList &joins, vector<JoinOrder> &join_orders) override;
+	void GenerateJoinOrders(const vector<idx_t> &hash_join_idxs, DependencyMap &dependencies, const JoinList &joins,
+	                        vector<JoinOrder> &join_orders) override;
 };
 
 } // namespace duckdb_polr

@@ -1,3 +1,4 @@
+#include <functional>
 // duckdb-polr_amd/host/polr_host_capi.cpp -- a small C surface over the host mirror classes so that
 // the Python test-suite (ctypes) can drive them: the multiplexer in isolation, POLARConfig's join-order
 // generation + bindings, the chunk-at-a-time PhysicalHashJoin, and the batch POLARPipelineExecutor.
@@ -160,6 +161,14 @@ int polr_host_generate_join_orders_ex(int enumerator, int routing, int k, int n_
                                       const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
                                       int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies,
                                       const uint64_t *node_card, const uint8_t *node_flags, int32_t *routing_out);
+// the same with NESTED build sides (a build side that is itself a join tree, JoinOrderNodeInfo::nested_join_order):
+// n_nodes >= k + 1 entries; node_parent[i] = -1 for the first k + 1, else the index of the node whose nested join order
+// node i belongs to (members in listing order: the nested tree's source first, then the build sides of its joins)
+int polr_host_generate_join_orders_nested(int enumerator, int routing, int k, int n_probe_cols, const int32_t *n_build_cols,
+                                          const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
+                                          int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies,
+                                          int n_nodes, const uint64_t *node_card, const uint8_t *node_flags,
+                                          const int32_t *node_parent, int32_t *routing_out);
 
 int polr_host_generate_join_orders(int enumerator, int routing, int k, int n_probe_cols, const int32_t *n_build_cols,
                                    const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
@@ -173,6 +182,16 @@ int polr_host_generate_join_orders_ex(int enumerator, int routing, int k, int n_
                                       const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
                                       int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies,
                                       const uint64_t *node_card, const uint8_t *node_flags, int32_t *routing_out) {
+	return polr_host_generate_join_orders_nested(enumerator, routing, k, n_probe_cols, n_build_cols, n_conds, cond_left_index,
+	                                             est_card, max_join_orders, paths, bindings, dependencies, k + 1, node_card,
+	                                             node_flags, nullptr, routing_out);
+}
+
+int polr_host_generate_join_orders_nested(int enumerator, int routing, int k, int n_probe_cols, const int32_t *n_build_cols,
+                                          const int32_t *n_conds, const int32_t *cond_left_index, const uint64_t *est_card,
+                                          int max_join_orders, int32_t *paths, int32_t *bindings, uint8_t *dependencies,
+                                          int n_nodes, const uint64_t *node_card, const uint8_t *node_flags,
+                                          const int32_t *node_parent, int32_t *routing_out) {
 	// routing_out (may be NULL): the routing the multiplexer ends up with -- DEFAULT_PATH when only Pipeline::Ready's
 	// BFS_MIN_CARD fallback found a bank (pipeline.cpp:216-225); paths must hold 26 rows in that case (24 + 2)
 	try {
@@ -186,11 +205,22 @@ int polr_host_generate_join_orders_ex(int enumerator, int routing, int k, int n_
 			raw.push_back(j.get());
 		}
 		if (node_card && node_flags) {
-			auto info = [&](int i) {
+			if (n_nodes < k + 1) {
+				throw InternalException("plan statistics for fewer nodes than the source and the joins' build sides");
+			}
+			std::function<JoinOrderNodeInfo(int)> info = [&](int i) {
 				JoinOrderNodeInfo ni;
 				ni.base_table_card = node_card[i];
 				ni.predicate = (node_flags[i] & 1) != 0;
 				ni.unique = (node_flags[i] & 2) != 0;
+				for (int c = k + 1; node_parent && c < n_nodes; c++) {
+					if (node_parent[c] == i) {
+						if (c <= i) {
+							throw InternalException("a nested plan node must be listed behind its parent");
+						}
+						ni.nested_join_order.push_back(info(c));
+					}
+				}
 				return ni;
 			};
 			raw.front()->probe_source_info = info(0);

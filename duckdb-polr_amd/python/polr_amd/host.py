@@ -49,6 +49,8 @@ def load():
     L.polr_host_generate_join_orders.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.polr_host_generate_join_orders_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                                     vp, vp, vp]
+    L.polr_host_generate_join_orders_nested.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp,
+                                                        vp, C.c_int, vp, vp, vp, vp]
     L.polr_host_run_pipeline.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, u64, u64, u64, vp, u64,
                                          C.c_int, vp, P(RunResult), vp, vp, vp, u64]
     L.polr_host_hash_join_probe.restype = C.c_int64
@@ -137,16 +139,29 @@ def generate_join_orders(enumerator, n_probe_cols, n_build_cols, cond_left_index
     bind = np.zeros((rows, k, 2), dtype=np.int32)
     deps = np.zeros((k, k), dtype=np.uint8)
     eff = C.c_int32(capi.ROUTING[routing])
-    ncard = nflags = None
+    ncard = nflags = nparent = None
+    n_nodes = 0
     if node_info is not None:
         assert len(node_info) == k + 1
-        ncard = np.ascontiguousarray([int(x[0]) for x in node_info], dtype=np.uint64)
-        nflags = np.ascontiguousarray([(1 if x[1] else 0) | (2 if x[2] else 0) for x in node_info], dtype=np.uint8)
-    n = L.polr_host_generate_join_orders_ex(ENUMERATOR[enumerator], capi.ROUTING[routing], k, n_probe_cols,
-                                            nb.ctypes.data, nc.ctypes.data, li.ctypes.data, card.ctypes.data,
-                                            max_join_orders, paths.ctypes.data, bind.ctypes.data, deps.ctypes.data,
-                                            None if ncard is None else ncard.ctypes.data,
-                                            None if nflags is None else nflags.ctypes.data, C.byref(eff))
+        # (base_table_card, predicate, unique[, nested]) -- nested: the join order of a build side that is itself a join
+        # tree, as a list of the same tuples (its source first); flattened behind the k + 1 top-level nodes
+        flat = [(x, -1) for x in node_info]
+        at = 0
+        while at < len(flat):
+            x = flat[at][0]
+            for inner in (x[3] if len(x) > 3 and x[3] else []):
+                flat.append((inner, at))
+            at += 1
+        n_nodes = len(flat)
+        ncard = np.ascontiguousarray([int(x[0][0]) for x in flat], dtype=np.uint64)
+        nflags = np.ascontiguousarray([(1 if x[0][1] else 0) | (2 if x[0][2] else 0) for x in flat], dtype=np.uint8)
+        nparent = np.ascontiguousarray([x[1] for x in flat], dtype=np.int32)
+    n = L.polr_host_generate_join_orders_nested(ENUMERATOR[enumerator], capi.ROUTING[routing], k, n_probe_cols,
+                                                nb.ctypes.data, nc.ctypes.data, li.ctypes.data, card.ctypes.data,
+                                                max_join_orders, paths.ctypes.data, bind.ctypes.data, deps.ctypes.data,
+                                                n_nodes, None if ncard is None else ncard.ctypes.data,
+                                                None if nflags is None else nflags.ctypes.data,
+                                                None if nparent is None else nparent.ctypes.data, C.byref(eff))
     if n < 0:
         raise RuntimeError(L.polr_host_last_error().decode())
     if n == 0:

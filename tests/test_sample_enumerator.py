@@ -49,3 +49,21 @@ def test_sample_is_deterministic_and_caps_at_factorial():
     assert a[0][0].tolist() == [0, 1, 2] and len(a[0]) <= 6
     rest = [tuple(p) for p in a[0][1:].tolist()]
     assert rest == sorted(set(rest))  # distinct, lexicographic (std::set<vector<idx_t>>)
+
+
+@pytest.mark.parametrize("case", ["q4.1-nested/3", "q4.1-nested/8"])
+def test_sample_over_a_nested_build_side_matches_reference(case):
+    """a build side that is itself a join tree (JoinOrderNode::nested_join_order, polar_enumeration_algo.cpp:262-280,
+    :401-409): the reference ran Q4.1 with its customer dimension written as (customer JOIN nation WHERE n_region = ...)
+    -- tests/golden/make_golden_nested.py; same pipeline and COUNT(*) as Q4.1, a different bank of join orders"""
+    gold = common.load_golden("sample_nested")
+    flat = common.load_golden("ssb_skew_sample")["cases"]["q4.1/3"]
+    c = gold["cases"][case]
+    assert c["count_star"] == flat["count_star"] and c["paths"] != flat["paths"]
+    k = len(c["node_info"]) - 1
+    info = [tuple(x) for x in c["node_info"]]
+    assert any(len(x) > 3 and x[3] for x in info)
+    got = phost.generate_join_orders("sample", 4, [0] * k, [[ssb_skew.PROBE_COLS.index(ssb_skew.DIM_KEY[n][1])]
+                                                           for n in ssb_skew.QUERY_JOINS["q4.1"]],
+                                     [1] * k, max_join_orders=c["max_join_orders"], node_info=info)
+    assert got is not None and got[0].tolist() == c["paths"]
