@@ -226,4 +226,34 @@ def workload(name, tables, q=None):
     if flt:
         wl["probe"]["filter"] = flt
         wl["probe"]["filter_sel"] = np.nonzero(probe_cols["f"] < flt[0][2])[0].astype(np.uint32)
+    wl["ref"] = _reference_form(probe, probe_cols, flt, order, joins)
     return wl
+
+
+def _reference_form(probe, probe_cols, flt, order, joins):
+    """how the same pipeline reads for the reference (oracle/ref_run.py): one table per alias -- the probe table with its
+    filter column, every build side with the rows its filters keep -- and the joins as a left-deep chain in pipeline order,
+    pinned with `SET disabled_optimizers TO 'join_order,...'`: the plan the reference executes is then one pipeline whose
+    source is the probe table and whose consecutive INNER hash joins are exactly these joins, so POLARConfig
+    (src/parallel/polar_config.cpp:19-71) multiplexes all of them."""
+    def tname(alias):
+        return "t_" + alias
+
+    def cname(alias, col):
+        return "%s__%s" % (alias, col)
+
+    tables = {tname(probe): {cname(probe, c): a for c, a in probe_cols.items()}}
+    sql = "SELECT COUNT(*) FROM %s" % tname(probe)
+    for (alias, bcol, src), j in zip(order, joins):
+        cols = {cname(alias, bcol): j["keys"][0]}
+        for c, a in j["payload"].items():
+            if c != bcol:
+                cols[cname(alias, c)] = a
+        tables[tname(alias)] = cols
+        sql += " JOIN %s ON %s = %s" % (tname(alias), cname(src[0], src[1]), cname(alias, bcol))
+    if flt:
+        sql += " WHERE " + " AND ".join("%s %s %d" % (cname(probe, c), op, const) for c, op, const in flt)
+    # (statistics propagation is switched off with the join order optimizer: on a reduced instance it finds build sides
+    # whose key ranges miss the probe side's, and replaces such a join -- and with it the pipeline -- by an empty result)
+    return {"tables": tables, "pk": {}, "query": sql,
+            "settings": ["SET disabled_optimizers TO 'join_order,statistics_propagation'"]}

@@ -11,6 +11,24 @@ from polr_amd import job_family as jf
 
 SHAPES = jf.shapes()
 SAMPLE = ["01a", "06d", "10c", "13b", "16b", "18a", "22c", "25a", "29a", "33c"]
+_TABLES = {}
+
+
+def _tables(scale):
+    if scale not in _TABLES:
+        _TABLES[scale] = jf.Tables(scale=scale)
+    return _TABLES[scale]
+
+
+def _matrix_sha(m):
+    import hashlib
+    return hashlib.sha1(np.ascontiguousarray(m, dtype=np.uint64).tobytes()).hexdigest()
+
+
+def _each_last_once(wl):
+    pn = list(wl["probe"]["cols"].keys())
+    return phost.generate_join_orders("each_last_once", len(pn), [len(j["payload"]) for j in wl["joins"]],
+                                      wl["cond_left_index"], [len(j["keys"][0]) for j in wl["joins"]], max_join_orders=8)[0]
 
 
 def test_all_113_queries_give_a_pipeline():
@@ -48,6 +66,73 @@ def _oracle(wl, paths, routing):
         offs = bench.chunk_offsets_for(sel, len(next(iter(wl["probe"]["cols"].values()))), 1024)
     return orc.run_pipeline(list(wl["probe"]["cols"].values()), oj, paths, routing=routing, caching=False,
                             collect_output=False, sel=sel, chunk_offsets=offs)
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_oracle_matches_the_reference_on_every_query(name):
+    """tests/golden/job_family.json (tests/golden/make_golden_job.py): the reference itself ran every one of the 113
+    pipelines as SQL over the synthetic tables -- join order pinned, so that its one POLAR pipeline multiplexes exactly the
+    joins of ours (src/parallel/polar_config.cpp:19-71) -- with ALTERNATE and with ADAPTIVE_REINIT routing; the oracle
+    reproduces the per-chunk x per-order intermediates (SHA-1 of the matrix, column sums), COUNT(*), the totals and the
+    adaptive trace"""
+    gold = common.load_golden("job_family")
+    g = gold["queries"][name]
+    wl = jf.workload(name, _tables(gold["scale"]), SHAPES[name])
+    assert [j["name"] for j in wl["joins"]] == g["joins"] and wl["ref"]["query"] == g["sql"]
+    paths = _each_last_once(wl)
+    assert len(paths) == g["n_join_orders"]
+    res = _oracle(wl, paths, "alternate")
+    assert res["alt_matrix"].shape == (g["n_chunks"], g["n_join_orders"])
+    assert res["alt_matrix"].sum(axis=0).tolist() == g["alternate_sums"]
+    assert _matrix_sha(res["alt_matrix"]) == g["alternate_sha1"]
+    assert res["num_output_rows"] == g["count_star"] and res["num_intermediates"] == g["alternate_intms"]
+    res = _oracle(wl, paths, "adaptive_reinit")
+    assert list(res["intermediates_per_round"]) == g["adaptive_rounds"] and res["num_intermediates"] == g["adaptive_intms"]
+    assert res["num_output_rows"] == g["count_star"]
+
+
+@pytest.mark.gpu
+def test_device_matches_the_reference_on_every_query(gpu_ctx):
+    """the same fixture on the device, all 113 pipelines through the C ABI: pool launch, one executor (the reference ran
+    single-threaded) -- ALTERNATE matrix bit-equal (SHA-1), COUNT(*), totals, and the ADAPTIVE_REINIT trace round by round"""
+    from polr_amd import capi
+    gold = common.load_golden("job_family")
+    t = _tables(gold["scale"])
+    for name in sorted(SHAPES):
+        g = gold["queries"][name]
+        wl = jf.workload(name, t, SHAPES[name])
+        pn = list(wl["probe"]["cols"].keys())
+        paths = _each_last_once(wl)
+        joins = capi.build_joins(gpu_ctx, wl, auto=True)
+        cols = list(wl["probe"]["cols"].values())
+        pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, paths)
+        flt = wl["probe"].get("filter")
+        if flt:
+            _n, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt])
+        else:
+            n_chunks = (len(cols[0]) + 1023) // 1024
+        k, P = len(wl["joins"]), len(paths)
+        assert P == g["n_join_orders"] and n_chunks == g["n_chunks"], name
+        for routing in ("alternate", "adaptive_reinit"):
+            mpx = capi.DeviceMultiplexer(pipe, routing, max_log_rounds=1 << 16)
+            if flt:
+                mpx.use_scan_chunks()
+            capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+            st = mpx.finish()
+            _, _, inter = mpx.fetch_log()
+            if routing == "alternate":
+                m = np.asarray(inter, dtype=np.uint64).reshape(-1, P)
+                assert m.sum(axis=0).tolist() == g["alternate_sums"] and _matrix_sha(m) == g["alternate_sha1"], name
+                assert st["num_intermediates"] == g["alternate_intms"], name
+                assert st["stage_out"][0][k - 1] == g["count_star"], name
+            else:
+                assert list(int(x) for x in inter) == g["adaptive_rounds"], name
+                assert st["num_intermediates"] == g["adaptive_intms"], name
+                assert sum(st["stage_out"][p][k - 1] for p in range(P)) == g["count_star"], name
+            mpx.close()
+        pipe.close()
+        for ht, _ in joins:
+            ht.close()
 
 
 @pytest.mark.gpu
