@@ -88,20 +88,23 @@ def chunk_offsets_for(sel, n_rows, V):
     return bounds[keep]
 
 
-def reference_runs(tables, pk, query, settings, n_tuples, repeat=5):
-    """the reference's POLAR pipeline on `tables` at 1 thread and at all host cores: {threads: (median ms, count)}"""
-    from oracle import ref_run
+def thread_ladder():
+    """1, 2, 4, ... up to this box's host cores (and the core count itself)"""
     nproc = os.cpu_count() or 1
-    out = {}
-    for threads in sorted(set([1, nproc])):
-        ms, wall, result = ref_run.time_polar_pipeline(tables, query, settings, threads, repeat=repeat, pk=pk)
-        count = None
-        try:
-            count = int(result.strip().splitlines()[1].split(",")[0])
-        except Exception:
-            pass
-        out[threads] = (float(np.median(ms)) if ms else None, count)
-    return out
+    ladder, t = [], 1
+    while t < nproc:
+        ladder.append(t)
+        t *= 2
+    ladder.append(nproc)
+    return ladder
+
+
+def reference_runs(tables, pk, query, settings, n_tuples, repeat=5, threads=None):
+    """the reference's POLAR pipeline on `tables` (loaded once) at every thread count of the ladder 1, 2, 4, ... host
+    cores: {threads: (median ms, count)}"""
+    from oracle import ref_run
+    got = ref_run.sweep_polar_pipeline(tables, query, settings, threads or thread_ladder(), repeat=repeat, pk=pk)
+    return {t: ((float(np.median(ms)) if ms else None), count) for t, (ms, count) in got.items()}
 
 
 def pick_baseline(runs, n_tuples):
@@ -135,11 +138,13 @@ def cpu_baseline_generic(wl, routing, n_tuples, enumerator):
         return None
     return {"value": best[0], "unit": "probe-tuples/s", "cores": best[1], "kind": "reference",
             "sample": "whole workload, median of 5 runs of the reference's POLAR pipeline (Pipeline::Schedule->Finalize "
-                      "incl. table scan + pushed-down filter + count sink), threads in {1,%d}; only runs whose COUNT(*) "
-                      "equals the single-threaded answer are candidates" % (os.cpu_count() or 1), **detail}
+                      "incl. table scan + pushed-down filter + count sink) at every thread count of %s; only runs whose "
+                      "COUNT(*) equals the single-threaded answer are candidates; `cores` = the best of them" % thread_ladder(),
+            "thread_sweep_tuples_per_s": {str(t): (None if ms is None else round(n_tuples / (ms / 1e3), 1))
+                                          for t, (ms, _c) in sorted(runs.items())}, **detail}
 
 
-def cpu_baseline_ssb(inst, query, routing, args, sample_rows):
+def cpu_baseline_ssb(inst, query, routing, args, sample_rows, dev=None):
     """SSB-skew: the reference on two CONTIGUOUS samples of lineorder, one from each skew phase (rows just below and
     just above the lo_orderkey 400 M mark would mix the phases; the samples start at 1/3 and at 5/6 of the table), full
     dimension tables with their PRIMARY KEYs, the same query, `sample` enumerator, same max_join_orders.  The table is
@@ -155,7 +160,14 @@ def cpu_baseline_ssb(inst, query, routing, args, sample_rows):
     detail = {"sample_rows_each": n, "sample_starts": starts}
     counts = []
     for ph, s0 in enumerate(starts):
-        cols = inst.lineorder(s0, s0 + n)
+        if dev is not None:
+            # (the same rows, generated on the device and copied back: the generator is one arithmetic in numpy and in
+            # torch -- tests/test_ssb_skew.py -- and 64 M rows take seconds there instead of a minute on the host)
+            ct = inst.lineorder_torch(s0, s0 + n, dev, cols=list(ssb_skew.PROBE_COLS))
+            cols = {c: ct[c].cpu().numpy().view(np.uint32) for c in ssb_skew.PROBE_COLS}
+            del ct
+        else:
+            cols = inst.lineorder(s0, s0 + n)
         ref = ssb_skew.reference_form(inst, query, cols)
         settings = list(ref["settings"]) + ["SET multiplexer_routing TO '%s'" % routing,
                                             "SET join_enumerator TO '%s'" % args.enumerator_name,
@@ -176,12 +188,19 @@ def cpu_baseline_ssb(inst, query, routing, args, sample_rows):
                 best = (v, threads)
     if not best:
         return None
+    sweep = {}
+    for threads, t in sorted(per_thread.items()):
+        if len(t) == 2:
+            sweep[str(threads)] = round(1.0 / (2.0 / 3.0 * t[0] + 1.0 / 3.0 * t[1]), 1)
     return {"value": best[0], "unit": "probe-tuples/s", "cores": best[1], "kind": "reference",
             "sample": "two contiguous samples of %d lineorder rows (rows %d.. of phase one, %d.. of phase two), full "
                       "dimension tables; median of 3 runs of the reference's POLAR pipeline each (Pipeline::Schedule->"
-                      "Finalize incl. table scan + count sink), threads in {1,%d}; value = 1 / (2/3 t1 + 1/3 t2), the "
-                      "phases' shares of the table; only runs whose COUNT(*) equals the single-threaded answer count"
-                      % (n, starts[0], starts[1], os.cpu_count() or 1),
+                      "Finalize incl. table scan + count sink) at every thread count of %s; value = 1 / (2/3 t1 + 1/3 t2), "
+                      "the phases' shares of the table, at the best thread count (`cores`) among those whose COUNT(*) "
+                      "equals the single-threaded answer in BOTH phases (the reference's multi-threaded POLAR pipeline "
+                      "has been seen to lose rows: such a run is listed, never used)"
+                      % (n, starts[0], starts[1], thread_ladder()),
+            "thread_sweep_tuples_per_s": sweep,
             "sample_count_star": counts, **detail}
 
 
@@ -601,7 +620,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         if with_cpu:
             try:
                 if is_ssb:
-                    cpu = cpu_baseline_ssb(inst, SSB_QUERIES[name], routing, args, args.cpu_sample_rows)
+                    cpu = cpu_baseline_ssb(inst, SSB_QUERIES[name], routing, args, args.cpu_sample_rows, dev=dev)
                 else:
                     cpu = cpu_baseline_generic(wl0, routing, n_tuples, enumerator)
                 if cpu:
@@ -985,7 +1004,7 @@ def main():
     ap.add_argument("--dir-prefix", default="", help="SET dir_prefix: prefix of the artefact file names")
     ap.add_argument("--nruns", type=int, default=1, help="benchmark_runner --nruns: logged / measured passes")
     ap.add_argument("--pin-path", type=int, default=None, help="measurement aid: make join order P of the bank path 0")
-    ap.add_argument("--cpu-sample-rows", type=int, default=8_000_000,
+    ap.add_argument("--cpu-sample-rows", type=int, default=64_000_000,
                     help="SSB-skew CPU baseline: rows of each of the two contiguous lineorder samples")
     args = ap.parse_args()
 

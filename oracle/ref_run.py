@@ -61,3 +61,43 @@ def time_polar_pipeline(tables, query, settings, threads, repeat=5, pk=None):
         return ms, wall, result
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
+
+
+def sweep_polar_pipeline(tables, query, settings, thread_counts, repeat=3, pk=None):
+    """Loads `tables` ONCE and runs `query` `repeat` times at every thread count of `thread_counts` (SET threads TO n) with
+    POLAR on and PRAGMA enable_measure_pipeline.  Returns {threads: (pipeline ms of each run, COUNT(*) or first result
+    cell of the last run)}."""
+    workdir = tempfile.mkdtemp(prefix="polr_cpu_baseline_")
+    try:
+        lines = []
+        for name, cols in tables.items():
+            lines += table_lines(workdir, name, cols, pk=(pk or {}).get(name))
+        for s_ in settings:
+            lines.append("sql " + s_)
+        lines.append("sql PRAGMA enable_polr")
+        lines.append("sql PRAGMA enable_measure_pipeline")
+        for t in thread_counts:
+            lines.append("sql SET threads TO %d" % t)
+            lines.append("repeat %d q_t%d %s" % (repeat, t, query))
+        script = os.path.join(workdir, "script.txt")
+        with open(script, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        outdir = os.path.join(workdir, "out")
+        proc = subprocess.run([DRIVER, script, outdir], capture_output=True, text=True, check=False)
+        if proc.returncode != 0:
+            raise RuntimeError("reference driver failed:\n" + proc.stdout + proc.stderr)
+        files = sorted(glob.glob(os.path.join(outdir, "tmp", "*-*.csv")), key=lambda f_: (os.path.getmtime(f_), f_))
+        files = [f_ for f_ in files if not f_.endswith("-enumeration.csv")]
+        ms = [float(open(f_).read().strip()) for f_ in files]
+        out = {}
+        for i, t in enumerate(thread_counts):
+            runs = ms[i * repeat:(i + 1) * repeat] if len(ms) == repeat * len(thread_counts) else []
+            cell = None
+            try:
+                cell = int(open(os.path.join(outdir, "q_t%d.csv" % t)).read().strip().splitlines()[1].split(",")[0])
+            except Exception:
+                pass
+            out[t] = (runs, cell)
+        return out
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)

@@ -291,3 +291,56 @@ def test_executors_with_a_list_of_ranges(gpu_ctx, R):
     for m in mpxs:
         m.close()
     pipe.close()
+
+
+def test_reference_runs_of_lip_and_backpressure_are_what_the_oracle_computes():
+    """tests/golden/lip_backpressure.json (tests/golden/make_golden_lip_bp.py): the reference with `PRAGMA enable_lip` (its
+    bloom pre-filter must not change COUNT(*); under enable_polr the reference itself dies with SIGSEGV on this pipeline,
+    so no run of LIP under the multiplexer exists to pin against) and with BACKPRESSURE routing at one thread -- where the
+    single task that gets to run takes the whole source down ITS join order, i.e. DEFAULT_PATH: same COUNT(*), same
+    intermediates"""
+    gold = common.load_golden("lip_backpressure")
+    wl, paths, c = workload("q4.1/3")
+    assert gold["lip_without_polar"]["count_star"] == c["count_star"] == gold["backpressure_threads_1"]["count_star"]
+    assert gold["lip_with_polar"]["returncode"] == -11  # (SIGSEGV: a defect of the reference, recorded as data)
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    res = orc.run_pipeline(pcols, ojoins, paths, routing="default_path", caching=False, collect_output=False)
+    assert res["num_output_rows"] == gold["backpressure_threads_1"]["count_star"]
+    assert [res["num_intermediates"]] == gold["backpressure_threads_1"]["intms_per_task"] == \
+        gold["default_path_threads_1"]["intms_per_task"]
+    assert gold["backpressure_threads_1"]["tuple_counts_printed"][0] == gold["source_rows"] == len(pcols[0])
+    # four threads: three tasks (one per join order that got a morsel), each reporting under ITS path 0; together the source
+    t4 = gold["backpressure_threads_4"]
+    assert t4["count_star"] == c["count_star"] and sum(t4["tuple_counts_printed"]) == gold["source_rows"]
+
+
+@pytest.mark.gpu
+def test_backpressure_matches_the_reference_run(gpu_ctx):
+    """BACKPRESSURE on the device against the reference's own runs: COUNT(*), every tuple taken exactly once, and -- with
+    row-group morsels (120 chunks = 122 880 rows, the reference's scan unit) -- the same morsel sizes dealt to the join
+    orders as the reference's four-thread run dealt to its tasks (which order gets which is timing on both sides)"""
+    from polr_amd import capi
+    gold = common.load_golden("lip_backpressure")
+    wl, paths, c = workload("q4.1/3")
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    cols = list(wl["probe"]["cols"].values())
+    n = len(cols[0])
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    k, P = len(wl["joins"]), len(paths)
+    mpxs = [capi.DeviceMultiplexer(pipe, "backpressure") for _ in range(P)]
+    capi.run_backpressure(mpxs, 0, n_chunks, 120)
+    stats = capi.finish_many(mpxs)
+    took = [sum(st["input_tuple_count_per_path"]) for st in stats]
+    assert sum(took) == n == gold["source_rows"]
+    assert sum(st["stage_out"][p][k - 1] for p, st in enumerate(stats)) == gold["backpressure_threads_4"]["count_star"]
+    morsels = sorted(x for x in gold["backpressure_threads_4"]["tuple_counts_printed"] if x)  # 54 240, 122 880, 122 880
+    assert sum(morsels) == n
+    # every executor's share is a sum of whole morsels of the reference's sizes
+    sums = {0}
+    for m_ in morsels:
+        sums |= {s_ + m_ for s_ in sums}
+    assert all(t_ in sums for t_ in took), (took, morsels)
+    for m in mpxs:
+        m.close()
+    pipe.close()
