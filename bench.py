@@ -587,6 +587,12 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
         if launches:
             sec = kernel_ms / 1e3 / steps
             achieved = alg / sec / 1e9
+            key_bytes = 0
+            for p_, path_ in enumerate(paths.tolist()):
+                inp_ = st["input_tuple_count_per_path"][p_]
+                for pos_, j_ in enumerate(path_):
+                    key_bytes += inp_ * joins_info[j_]["key_bytes"]
+                    inp_ = st["stage_out"][p_][pos_]
             working_set = sum(t.numel() * t.element_size() for t in tens) + \
                 sum(int(j[0].info()["device_bytes"]) for j in joins)
             roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -601,6 +607,10 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                     "launches_per_step": launches / steps,
                     "ms_per_step_with_events": round(dt_events / steps * 1e3, 4),
                     "working_set_bytes": int(working_set),
+                    # the bytes this design cannot avoid moving: one key per tuple ENTERING each stage (the SURVEY formula
+                    # also credits a bitmap byte per lookup and 8 B of selection writes per match, which live in LDS here)
+                    "key_bytes_per_step": int(key_bytes),
+                    "frac_key_bytes": round(key_bytes / sec / 1e9 / HBM_PEAK_GBS, 5),
                     "note": "one launch = the whole pass: every executor's routing loop and all probe rounds (the kernel "
                             "time includes the device-side waits between dependent routing rounds)"}
             sig = {"workload": name, "scale": float(scale), "routing": routing, "join_enumerator": enumerator,

@@ -1183,6 +1183,9 @@ static void plan_flat(polr_pipeline *p, std::vector<StageDesc> &sd_count) {
 		used += padded;
 	}
 	c.lds_table_dwords = used;
+	// (an emitting run needs every join's build id: a perfect table's is the key's offset, a hash table's would take a
+	// second probe -- such banks emit through the generic pipeline)
+	p->flat_emit = order.size() == c.k;
 	for (uint32_t q = 0; q < c.n_paths; q++) {
 		for (uint32_t pos = 0; pos < c.k; pos++) {
 			sd_count[(size_t)q * POLR_KMAX + pos].lds_off1 = off_of_join[c.paths[q].order[pos]];

@@ -60,6 +60,7 @@ struct FlatStage {
 	const POLR_GLOBAL uint32_t *table; // bit words or {key,row} slots in HBM
 	uint32_t kind_lds;     // kind | lds_off1 << 8 (lds_off1: 1 + dword offset inside the workgroup's LDS table area, 0 = HBM)
 	uint32_t a, b;         // perfect: min, range (32-bit modular); hash: slot mask (capacity <= 2^31), unused
+	uint32_t out_slot;     // emitting runs: the output slot of this join's build id (1 + its index in the original order)
 };
 
 __device__ __forceinline__ uint32_t flat_uni(uint32_t v) {
@@ -69,9 +70,10 @@ __device__ __forceinline__ uint64_t flat_uni64(uint64_t v) {
 	return ((uint64_t)flat_uni((uint32_t)(v >> 32)) << 32) | flat_uni((uint32_t)v);
 }
 
-__device__ __forceinline__ FlatStage flat_load_stage(const StageDesc *d_generic) {
+__device__ __forceinline__ FlatStage flat_load_stage(const StageDesc *d_generic, uint32_t join_index) {
 	const POLR_GLOBAL StageDesc *d = as_global(d_generic);
 	FlatStage s;
+	s.out_slot = 1u + join_index;
 	s.keys = as_global((const uint32_t *)flat_uni64((uint64_t)d->key_data[0]));
 	s.valid = as_global((const uint8_t *)flat_uni64((uint64_t)d->key_valid[0]));
 	s.table = as_global((const uint32_t *)flat_uni64((uint64_t)d->table));
@@ -91,6 +93,11 @@ struct FlatCtx {
 	POLR_LDS uint16_t *q;                // this wave's queues
 	uint32_t qsize[K], cnt[K];
 	uint64_t unit_begin, in_pos, in_end;
+	// emitting runs (a materialising sink behind a bank of perfect tables): the final tuples as row ids, chunked like a
+	// DataChunk stream -- slot 0 the probe row, slot 1 + j the build id of join j = its key's offset in the perfect table
+	DevOut out;
+	bool emit, overflow;
+	uint32_t cur_chunk, fill;
 	// stage 0's next step, requested one step ahead (the key stream's HBM round trip overlaps the current step)
 	uint4 pf0, pf1;
 	uint64_t pf_pos; // source position the prefetched keys belong to; ~0: none
@@ -203,11 +210,81 @@ __device__ __forceinline__ void flat_lookup(const FlatStage &s, const POLR_LDS u
 	}
 }
 
+#define FLAT_NO_CHUNK 0xFFFFFFFFu
+// the tuples that survived the last join leave as row ids (emitting runs): the probe row, and for every join the build id
+// its key stands for -- every join of an emitting flat pipeline is a perfect table, whose build id IS key - min
+// (RowOperations::Gather reads payload columns re-ordered that way: polr_gather.hip) -- re-read from the probe columns
+// for the few tuples that get this far
+template <int K>
+__device__ __forceinline__ void flat_out_write(FlatCtx<K> &c, uint32_t pos, bool valid) {
+	const uint64_t m = __ballot(valid);
+	const uint32_t n = (uint32_t)__popcll(m);
+	if (n == 0) {
+		return;
+	}
+	const uint32_t rank = flat_rank(m);
+	POLR_GLOBAL uint32_t *ids = as_global(c.out.ids);
+	POLR_GLOBAL uint32_t *chunk_count = as_global(c.out.chunk_count);
+	uint32_t row = 0, id[K];
+	if (valid) {
+		const uint64_t tp = c.unit_begin + pos;
+		row = c.sel ? c.sel[tp] : (uint32_t)tp;
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			id[p] = p < (int)c.k ? c.st[p].keys[row] - c.st[p].a : 0u;
+		}
+	}
+	uint32_t done = 0;
+	while (done < n) {
+		if (c.cur_chunk == FLAT_NO_CHUNK || c.fill == c.out.chunk_capacity) {
+			if (c.cur_chunk != FLAT_NO_CHUNK && c.lane == 0) {
+				chunk_count[c.cur_chunk] = c.fill;
+			}
+			uint32_t nc = 0;
+			if (c.lane == 0) {
+				nc = atomicAdd(&c.out.cursor[0], 1u);
+			}
+			nc = flat_uni(nc);
+			if (nc >= c.out.max_chunks) {
+				if (c.lane == 0) {
+					atomicExch(&c.out.cursor[1], 1u);
+				}
+				c.overflow = true;
+				c.cur_chunk = FLAT_NO_CHUNK;
+				c.emit = false;
+				return;
+			}
+			c.cur_chunk = nc;
+			c.fill = 0;
+		}
+		const uint32_t room = c.out.chunk_capacity - c.fill;
+		const uint32_t take = (n - done) < room ? (n - done) : room;
+		if (valid && rank >= done && rank < done + take) {
+			const uint64_t base = (uint64_t)c.cur_chunk * c.out.chunk_capacity + c.fill + (rank - done);
+			ids[base] = row;
+#pragma unroll
+			for (int p = 0; p < K; p++) {
+				if (p < (int)c.k) {
+					ids[(uint64_t)c.st[p].out_slot * c.out.slot_stride + base] = id[p];
+				}
+			}
+		}
+		c.fill += take;
+		done += take;
+	}
+}
+
 // survivors of stage POS: count them; push their unit positions to the next stage's queue unless POS is the last join
 template <int K, int POS, int F>
 __device__ __forceinline__ void flat_emit(FlatCtx<K> &c, const uint32_t (&pos)[F], const bool (&hit)[F]) {
 	const bool last = POS + 1 >= K || POS + 1 == (int)c.k;
 	uint32_t total = 0;
+	if (last && c.emit) {
+#pragma unroll
+		for (int i = 0; i < F; i++) {
+			flat_out_write<K>(c, pos[i], hit[i]);
+		}
+	}
 	if constexpr (POS + 1 < K) {
 		POLR_LDS uint16_t *qq = c.q + flat_qoff<K>(POS + 1);
 		uint32_t qs = c.qsize[POS + 1];

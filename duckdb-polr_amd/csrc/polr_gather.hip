@@ -138,7 +138,7 @@ hipError_t polr_launch_poolg_kernelx(uint32_t W, uint32_t k, uint32_t n_blocks, 
 	int polr_pool_flat_occupancy_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                              \
 	hipError_t polr_launch_pool_flat_kernel_k##KK(uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords, \
 	                                              hipStream_t stream, const DevPipeline *pipe,                        \
-	                                              const ResidentExec *execs, PoolRun *run);
+	                                              const ResidentExec *execs, PoolRun *run, DevOut out);
 DECL_POOL_K(2)
 DECL_POOL_K(4)
 DECL_POOL_K(6)
@@ -245,9 +245,9 @@ extern "C++" int polr_pool_flat_occupancy(uint32_t k, uint32_t wpb, uint32_t tab
 
 extern "C++" hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t wpb, uint32_t table_dwords,
                                                      hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                                     PoolRun *run) {
-	POOL_SWITCH(k, polr_launch_pool_flat_kernel_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run),
-	            polr_launch_pool_flat_kernel_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run),
-	            polr_launch_pool_flat_kernel_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run),
-	            polr_launch_pool_flat_kernel_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run))
+                                                     PoolRun *run, DevOut out) {
+	POOL_SWITCH(k, polr_launch_pool_flat_kernel_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
+	            polr_launch_pool_flat_kernel_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
+	            polr_launch_pool_flat_kernel_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
+	            polr_launch_pool_flat_kernel_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out))
 }

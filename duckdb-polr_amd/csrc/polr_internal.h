@@ -99,6 +99,7 @@ struct polr_pipeline {
 	int blocks_per_cu_count = 0, blocks_per_cu_mat = 0;       // measured residency of the path kernel
 	uint32_t wpb_count = 0, wpb_mat = 0;                      // waves per workgroup (4, or fewer when the LDS queues are wide)
 	uint32_t flat_wpb = 0;                                    // flat pipelines: waves per workgroup of the flat pool kernel
+	bool flat_emit = false;                                   // ... and every join is a perfect table: emitting runs take it too
 	// launch scratch (grown on demand)
 	DevRound *rounds_dev = nullptr;
 	uint64_t *prefix_dev = nullptr;
@@ -166,7 +167,7 @@ size_t polr_pool_flat_wave_bytes(uint32_t k);
 int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
 hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords,
                                         hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                        PoolRun *run);
+                                        PoolRun *run, DevOut out);
 void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,

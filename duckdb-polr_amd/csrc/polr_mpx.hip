@@ -291,8 +291,8 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
 	polr_ctx *ctx = p->ctx;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	const bool mat = materialize != 0;
-	const DevPipeline &dp = mat ? p->host_mat : p->host_count;
-	const bool flat = !mat && dp.flat != 0;
+	const bool flat = p->host_count.flat != 0 && (!mat || p->flat_emit);
+	const DevPipeline &dp = (mat && !flat) ? p->host_mat : p->host_count;
 	const uint32_t wq = dp.W + (dp.mult ? 1u : 0u); // slots per queued tuple in the pool launch: ids (+ multiplicity)
 	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, wq);
 	memset(info, 0, sizeof(*info));
@@ -569,8 +569,10 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = stream ? (hipStream_t)stream : m0->own_stream;
 	const bool materialize = out != nullptr;
-	const DevPipeline &dp = materialize ? p->host_mat : p->host_count;
-	const bool flat = !materialize && dp.flat != 0;
+	// a bank of single-key unique-match joins takes the flat pipeline -- counting runs always, emitting runs when every
+	// join is a perfect table (polr_flat_device.h); it runs on the counting variant's descriptors either way
+	const bool flat = p->host_count.flat != 0 && (!materialize || p->flat_emit);
+	const DevPipeline &dp = (materialize && !flat) ? p->host_mat : p->host_count;
 	const uint32_t wq = dp.W + (dp.mult ? 1u : 0u); // slots per queued tuple: ids (+ multiplicity)
 	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, wq);
 	int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
@@ -759,7 +761,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	const ResidentExec *execs_dev = (const ResidentExec *)(m0->execs_dev + POOL_HEADER_BYTES);
 	hipError_t e =
 	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
-	                                        (PoolRun *)m0->execs_dev)
+	                                        (PoolRun *)m0->execs_dev, dout)
 	         : polr_launch_pool_kernel(wq, dp.k, n_blocks, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
 	                                   (PoolRun *)m0->execs_dev, dout, dp.ext != 0);
 	if (e != hipSuccess) {

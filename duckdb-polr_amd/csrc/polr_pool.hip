@@ -29,7 +29,7 @@ POOL_DIAG_ENTRY(PASTE_TL(polr_diag_router_k, POLR_K), PASTE_TL(polr_diag_timelin
 template <int K>
 __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline *__restrict__ pipe,
                                                               const ResidentExec *__restrict__ execs, PoolRun *run,
-                                                              uint32_t lds_per_wave, uint32_t table_dwords,
+                                                              DevOut out, uint32_t lds_per_wave, uint32_t table_dwords,
                                                               uint32_t router_dwords) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -70,8 +70,13 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		c.st[p].keys = nullptr;
 		c.st[p].valid = nullptr;
 		c.st[p].table = nullptr;
-		c.st[p].kind_lds = c.st[p].a = c.st[p].b = 0;
+		c.st[p].kind_lds = c.st[p].a = c.st[p].b = c.st[p].out_slot = 0;
 	}
+	c.out = out;
+	c.emit = false;
+	c.overflow = false;
+	c.cur_chunk = FLAT_NO_CHUNK;
+	c.fill = 0;
 	c.unit_begin = c.in_pos = c.in_end = 0;
 	c.pf_pos = ~0ull;
 	c.pf0 = make_uint4(0, 0, 0, 0);
@@ -91,11 +96,12 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 #pragma unroll
 			for (int p = 0; p < K; p++) {
 				if (p < (int)k) {
-					c.st[p] = flat_load_stage(stages + (uint64_t)u.path * POLR_KMAX + p);
+					c.st[p] = flat_load_stage(stages + (uint64_t)u.path * POLR_KMAX + p, uni(pipe->paths[u.path].order[p]));
 				}
 			}
 			cur_path = u.path;
 		}
+		c.emit = u.emit != 0 && out.ids != nullptr && !c.overflow;
 		c.unit_begin = u.begin;
 		c.in_pos = u.begin;
 		c.in_end = (uint64_t)u.begin + u.count;
@@ -120,6 +126,9 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 			have = peek == POLR_POLL_WORK;
 		}
 		u = nxt;
+	}
+	if (c.cur_chunk != FLAT_NO_CHUNK && c.lane == 0) {
+		out.chunk_count[c.cur_chunk] = c.fill;
 	}
 }
 
@@ -174,7 +183,7 @@ extern "C++" int PASTE(polr_pool_flat_occupancy_k, POLR_K)(uint32_t waves_per_bl
 extern "C++" hipError_t PASTE(polr_launch_pool_flat_kernel_k, POLR_K)(uint32_t n_blocks, uint32_t waves_per_block,
                                                                       uint32_t table_dwords, hipStream_t stream,
                                                                       const DevPipeline *pipe, const ResidentExec *execs,
-                                                                      PoolRun *run) {
+                                                                      PoolRun *run, DevOut out) {
 	const size_t dwords = pool_flat_lds_dwords(waves_per_block, table_dwords);
 	const size_t lds = dwords * sizeof(uint32_t);
 	hipError_t e = pool_flat_prepare(lds);
@@ -184,7 +193,7 @@ extern "C++" hipError_t PASTE(polr_launch_pool_flat_kernel_k, POLR_K)(uint32_t n
 	uint32_t per_wave = (uint32_t)pool_flat_wave_dwords();
 	uint32_t router_dwords = (uint32_t)(dwords / waves_per_block);
 	dim3 grid(n_blocks), block(64 * waves_per_block);
-	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&per_wave, (void *)&table_dwords,
+	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&out, (void *)&per_wave, (void *)&table_dwords,
 	                (void *)&router_dwords};
 	return hipLaunchKernel((const void *)polr_pool_flat_kernel<POLR_K>, grid, block, args, lds, stream);
 }

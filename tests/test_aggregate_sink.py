@@ -262,3 +262,86 @@ def test_device_ssb_q41_groups_match_reference(gpu_ctx, routing):
     assert sum(v[0] for v in vals2) == sum(r[2] for r in Q41["rows"] if r[0] == y0)
     mpx.close()
     pipe.close()
+
+
+def _q41_shipped_want():
+    gold = common.load_golden("ssb_q41_groupby")
+    return gold, {(r[0], r[1]): r[2] for r in gold["rows"]}
+
+
+def test_oracle_q41_as_shipped_matches_reference():
+    """benchmark/ssb-skew/queries/q4-1.sql with its own select list on the load.sql-exact instance (polr_amd/ssb_skew.py):
+    the reference's GROUP BY d_year, c_nation answer (tests/golden/ssb_q41_groupby.json) from the oracle's pipeline output"""
+    from polr_amd import ssb_skew
+    gold, want = _q41_shipped_want()
+    wl = ssb_skew.workload("q4.1", **gold["shape"])
+    inst = wl["instance"]
+    m = inst.lineorder(0, inst.n_lo, cols=["lo_revenue", "lo_supplycost"])
+    pcols, pvalid, joins = common.oracle_joins(wl)
+    k = len(joins)
+    res = orc.run_pipeline(pcols, joins, [list(range(k))], routing="default_path")
+    rows = res["out_rows"]
+    rev, _ = orc.materialize_column(rows, k, -1, m["lo_revenue"], None)
+    sup, _ = orc.materialize_column(rows, k, -1, m["lo_supplycost"], None)
+    nat, _ = orc.materialize_column(rows, k, 0, wl["joins"][0]["payload"]["c_nation"], None)
+    yr, _ = orc.materialize_column(rows, k, 3, wl["joins"][3]["payload"]["d_year"], None)
+    got = {}
+    for y, c, r, s in zip(yr.tolist(), nat.tolist(), rev.tolist(), sup.tolist()):
+        got[(y, c)] = got.get((y, c), 0) + r - s
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_exec", [1, 16])
+def test_device_q41_as_shipped_on_the_flat_pipeline(gpu_ctx, n_exec):
+    """Q4.1 with its own sink, on the device: the FLAT pipeline (bit tables in LDS) emits the surviving tuples' row ids
+    -- probe row + per join the key's offset in its perfect table -- and the perfect-hash aggregate groups them by
+    d_year, c_nation; profit = SUM(lo_revenue) - SUM(lo_supplycost).  Against the reference's answer; and the emitted row
+    set against numpy"""
+    from polr_amd import capi, ssb_skew
+    gold, want = _q41_shipped_want()
+    wl = ssb_skew.workload("q4.1", **gold["shape"])
+    inst = wl["instance"]
+    m = inst.lineorder(0, inst.n_lo, cols=["lo_revenue", "lo_supplycost"])
+    names = list(wl["probe"]["cols"].keys()) + ["lo_revenue", "lo_supplycost"]
+    cols = list(wl["probe"]["cols"].values()) + [m["lo_revenue"], m["lo_supplycost"]]
+    n = len(cols[0])
+    paths = np.asarray(common.load_golden("ssb_skew_sample")["cases"]["q4.1/3"]["paths"], dtype=np.int32)
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    assert pipe.launch_info(True)["flat"] == 1, "an emitting run over perfect tables must take the flat pipeline"
+    out = capi.Output(pipe, 1024, 16384)
+    n_chunks = (n + 1023) // 1024
+    mpxs = [capi.DeviceMultiplexer(pipe, "adaptive_reinit") for _ in range(n_exec)]
+    capi.run_resident(mpxs, [((e * n_chunks) // n_exec, ((e + 1) * n_chunks) // n_exec) for e in range(n_exec)], out=out,
+                      reset=True, finish=True)
+    stats = capi.finish_many(mpxs)
+    k = len(wl["joins"])
+    ids = out.fetch_ids()
+    assert len(ids) == sum(sum(st["stage_out"][p][k - 1] for p in range(len(paths))) for st in stats) == sum(
+        1 for _ in ids)
+    # the emitted row set: exactly the probe rows whose four keys are on their build sides, each once
+    keep = np.ones(n, dtype=bool)
+    for j in wl["joins"]:
+        keep &= np.isin(cols[j["key_src"][0][1]], j["keys"][0])
+    assert np.array_equal(np.sort(ids[:, 0]), np.nonzero(keep)[0].astype(np.uint32))
+    for x, j in enumerate(wl["joins"]):  # slot 1 + j: the key's offset in join j's perfect table
+        assert np.array_equal(ids[:, 1 + x].astype(np.int64), cols[j["key_src"][0][1]][ids[:, 0]].astype(np.int64) - int(j["keys"][0].min()))
+    years = sorted({y for y, _c in want})
+    y0, ny = years[0], years[-1] - years[0] + 1
+    keys = [(3, 0, y0, ny), (0, 0, 0, 50)]  # d_year (payload 0 of join 3), c_nation (payload 0 of join 0)
+    specs = [("count_star", -1, 0), ("sum", -1, names.index("lo_revenue")), ("sum", -1, names.index("lo_supplycost"))]
+    vals, counts, dropped = out.aggregate_grouped(keys, specs)
+    assert dropped == 0
+    seen = 0
+    for g_, v in enumerate(vals):
+        key = (y0 + g_ // 50, g_ % 50)
+        if key in want:
+            assert v[1] - v[2] == want[key], key
+            seen += 1
+        else:
+            assert v[0] == 0
+    assert seen == len(want) and sum(v[0] for v in vals) == len(ids)
+    for m_ in mpxs:
+        m_.close()
+    pipe.close()
