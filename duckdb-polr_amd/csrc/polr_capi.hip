@@ -95,6 +95,15 @@ int polr_ctx_sync(polr_ctx *ctx, void *stream) {
 	return POLR_OK;
 }
 
+int polr_ctx_get_stream(polr_ctx *ctx, void **stream) {
+	POLR_ENTRY();
+	if (!ctx || !stream) {
+		return POLR_E_INVALID;
+	}
+	*stream = (void *)ctx->stream;
+	return POLR_OK;
+}
+
 int polr_ctx_set_pool_tuning(polr_ctx *ctx, const polr_pool_tuning *t) {
 	POLR_ENTRY();
 	if (!ctx) {

@@ -34,7 +34,7 @@ EXPORTS = [
     "polr_mpx_destroy", "polr_mpx_reset", "polr_mpx_enable_timing", "polr_mpx_kernel_time", "polr_mpx_run_many", "polr_mpx_finish_many", "polr_mpx_run_resident", "polr_mpx_run_resident_ranges", "polr_mpx_run_resident_morsels",
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
-    "polr_ctx_set_pool_tuning",
+    "polr_ctx_set_pool_tuning", "polr_ctx_get_stream",
 ]
 
 
@@ -134,6 +134,7 @@ def load():
     L.polr_last_error.restype = C.c_char_p
     L.polr_ctx_sync.argtypes = [vp, vp]
     L.polr_ctx_set_pool_tuning.argtypes = [vp, C.POINTER(PoolTuning)]
+    L.polr_ctx_get_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.polr_ht_upload_rows.argtypes = [vp, vp, u64, u32, vp, vp, vp, u32, u32, P(vp)]
     L.polr_ht_upload_columns.argtypes = [vp, P(Col), u32, P(Col), u32, u64, P(vp)]
     L.polr_ht_finalize_hash.argtypes = [vp, vp]
@@ -230,6 +231,13 @@ class Context:
 
     def sync(self, stream=None):
         self.check(self.L.polr_ctx_sync(self.h, stream))
+
+    def stream(self):
+        """the context's own stream (polr_ctx_get_stream), to pass to run_resident so that a run is in line with
+        Output.reset before it and the aggregates behind it"""
+        st = C.c_void_p()
+        self.check(self.L.polr_ctx_get_stream(self.h, C.byref(st)))
+        return st
 
     def set_pool_tuning(self, **kw):
         """polr_ctx_set_pool_tuning; no arguments = every default.  hi_tuples=N is passed as hi_tuples_p1 = N + 1"""
@@ -622,7 +630,7 @@ def _stats_dict(st, P, k):
 RUN_RESET, RUN_FINISH = 1, 2
 
 
-def run_resident(mpxs, ranges, out=None, reset=False, finish=False, share=1):
+def run_resident(mpxs, ranges, out=None, reset=False, finish=False, share=1, stream=None):
     """polr_mpx_run_resident: the same run as ONE launch (device-resident routing loop);
     reset / finish fold polr_mpx_reset / the closing FinalizePathRun into the same launch"""
     ctx = mpxs[0].ctx
@@ -630,7 +638,7 @@ def run_resident(mpxs, ranges, out=None, reset=False, finish=False, share=1):
     hs = (C.c_void_p * n)(*[m.h for m in mpxs])
     b = np.ascontiguousarray([r[0] for r in ranges], dtype=np.uint64)
     e = np.ascontiguousarray([r[1] for r in ranges], dtype=np.uint64)
-    ctx.check(ctx.L.polr_mpx_run_resident(hs, None, b.ctypes.data, e.ctypes.data, n, out.h if out else None,
+    ctx.check(ctx.L.polr_mpx_run_resident(hs, stream, b.ctypes.data, e.ctypes.data, n, out.h if out else None,
                                           (RUN_RESET if reset else 0) | (RUN_FINISH if finish else 0) | ((share & 0xFF) << 8 if share > 1 else 0)))
 
 

@@ -231,7 +231,7 @@ def workload(name, tables, q=None):
 
 
 def _reference_form(probe, probe_cols, flt, order, joins):
-    """how the same pipeline reads for the reference (oracle/ref_run.py): one table per alias -- the probe table with its
+    """how the same pipeline reads for the reference (as SQL over uploaded tables): one table per alias -- the probe table with its
     filter column, every build side with the rows its filters keep -- and the joins as a left-deep chain in pipeline order,
     pinned with `SET disabled_optimizers TO 'join_order,...'`: the plan the reference executes is then one pipeline whose
     source is the probe table and whose consecutive INNER hash joins are exactly these joins, so POLARConfig

@@ -83,6 +83,10 @@ int polr_ctx_create(int device_id, polr_ctx **out);
 void polr_ctx_destroy(polr_ctx *ctx);
 const char *polr_last_error(const polr_ctx *ctx);
 int polr_ctx_sync(polr_ctx *ctx, void *stream);
+/* The context's own stream (what `stream == NULL` means for every call except the multiplexer runs, which default to a
+ * stream of the first multiplexer): pass it to polr_mpx_run_resident* to put a run in line with polr_out_reset before
+ * it and polr_out_aggregate* behind it -- a pass with its sink is then one ordered sequence, no host synchronisation. */
+int polr_ctx_get_stream(polr_ctx *ctx, void **stream);
 /* Tuning of the pool launch (polr_mpx_run_resident*): how a context's runs cut rounds into units and how its probe
  * waves poll.  A field left 0 keeps the library's default; NULL restores every default.  Results never depend on any
  * of these (only speed does), except watchdog_us, which bounds how long a router waits for its probe waves before the

@@ -65,8 +65,8 @@ def time_polar_pipeline(tables, query, settings, threads, repeat=5, pk=None):
 
 def sweep_polar_pipeline(tables, query, settings, thread_counts, repeat=3, pk=None):
     """Loads `tables` ONCE and runs `query` `repeat` times at every thread count of `thread_counts` (SET threads TO n) with
-    POLAR on and PRAGMA enable_measure_pipeline.  Returns {threads: (pipeline ms of each run, COUNT(*) or first result
-    cell of the last run)}."""
+    POLAR on and PRAGMA enable_measure_pipeline.  Returns {threads: (pipeline ms of each run, the answer of the last run:
+    COUNT(*) itself for a one-cell result, else the CRC-32 of the result's rows)}."""
     workdir = tempfile.mkdtemp(prefix="polr_cpu_baseline_")
     try:
         lines = []
@@ -94,7 +94,12 @@ def sweep_polar_pipeline(tables, query, settings, thread_counts, repeat=3, pk=No
             runs = ms[i * repeat:(i + 1) * repeat] if len(ms) == repeat * len(thread_counts) else []
             cell = None
             try:
-                cell = int(open(os.path.join(outdir, "q_t%d.csv" % t)).read().strip().splitlines()[1].split(",")[0])
+                rows = open(os.path.join(outdir, "q_t%d.csv" % t)).read().strip().splitlines()[1:]
+                if len(rows) == 1 and "," not in rows[0]:
+                    cell = int(rows[0])  # COUNT(*)
+                else:
+                    import zlib
+                    cell = zlib.crc32("\n".join(rows).encode())  # a whole result: its checksum stands for it
             except Exception:
                 pass
             out[t] = (runs, cell)
