@@ -1056,7 +1056,16 @@ def run_q41_shipped(args, env, steps, warmup, with_cpu):
             if cpu:
                 cpu["value"] = round(cpu["value"], 1)
         except Exception as e:
-            cpu = {"value": None, "error": str(e)[-600:]}
+            # (seen on the 256-thread GPU hosts: the reference answers its own shipped SQL with "Invalid Error:
+            # vector::reserve" at every thread count -- on the 8-core build container it runs it, at 57 M tuples/s on one
+            # thread.  The COUNT(*) form of the same pipeline on the same samples is timed instead and labelled as such.)
+            err = str(e)[-400:]
+            try:
+                cpu = cpu_baseline_ssb(inst, query, routing, args, min(args.cpu_sample_rows, 16_000_000), dev=dev)
+                cpu["value"] = round(cpu["value"], 1)
+                cpu["sink"] = "COUNT(*) -- the reference failed on the shipped select list on this host: " + err
+            except Exception as e2:
+                cpu = {"value": None, "error": err + " / " + str(e2)[-300:]}
     rec = {"metric": "probe-tuples/s", "value": round(n * steps / dt, 1), "unit": "tuples/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
