@@ -520,3 +520,269 @@ extern "C" int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_
 	}
 	return POLR_OK;
 }
+
+
+// ---- VARCHAR: string heaps on the device and the MIN / MAX sink over string_t cells -------------------------------------
+// (string_type.hpp:23-28: {u32 length, char inlined[12]} or {u32 length, char prefix[4], char *ptr})
+__global__ __launch_bounds__(256) void polr_rebase_strings_kernel(uint4 *cells, uint64_t n, uint64_t host_base, uint64_t host_end,
+                                                                  uint64_t dev_base, unsigned long long *outside) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	uint4 c = cells[i];
+	if (c.x > 12u) {
+		const uint64_t ptr = ((uint64_t)c.w << 32) | c.z;
+		if (ptr < host_base || ptr + c.x > host_end) {
+			atomicAdd(outside, 1ull); // (a cell pointing outside the heap it was said to live in)
+			return;
+		}
+		const uint64_t moved = ptr - host_base + dev_base;
+		c.z = (uint32_t)moved;
+		c.w = (uint32_t)(moved >> 32);
+		cells[i] = c;
+	}
+}
+
+__device__ __forceinline__ uint32_t str_byte(const uint4 &c, uint32_t i) {
+	if (c.x <= 12u) {
+		const uint32_t w = i < 4 ? c.y : (i < 8 ? c.z : c.w);
+		return (w >> (8u * (i & 3u))) & 0xFFu;
+	}
+	if (i < 4) {
+		return (c.y >> (8u * i)) & 0xFFu;
+	}
+	const uint8_t *p = (const uint8_t *)(((uint64_t)c.w << 32) | c.z);
+	return p[i];
+}
+
+// a < b in the order of the reference's string comparison: unsigned bytes, a proper prefix first
+__device__ __forceinline__ bool str_less(const uint4 &a, const uint4 &b) {
+	const uint32_t n = a.x < b.x ? a.x : b.x;
+	// the first four characters sit in the same place in both forms
+	const uint32_t pa = __builtin_bswap32(a.y), pb = __builtin_bswap32(b.y);
+	if (n >= 4 && pa != pb) {
+		return pa < pb;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t x = str_byte(a, i), y = str_byte(b, i);
+		if (x != y) {
+			return x < y;
+		}
+	}
+	return a.x < b.x;
+}
+
+struct StrPartial {
+	uint4 cell;
+	uint32_t have;
+	uint32_t pad[3];
+};
+
+// phase 1: per workgroup the extreme of its share of the output rows; phase 2 (one workgroup, n_in partials): the extreme
+__global__ __launch_bounds__(256) void polr_agg_string_kernel(DevOut out, uint32_t n_chunks, DevCol src, uint32_t slot, int want_max,
+                                                              const StrPartial *__restrict__ in, uint32_t n_in,
+                                                              StrPartial *__restrict__ partials) {
+	__shared__ StrPartial wave_part[4];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint4 best = make_uint4(0, 0, 0, 0);
+	bool have = false;
+	auto offer = [&](const uint4 &c) {
+		if (!have || (want_max ? str_less(best, c) : str_less(c, best))) {
+			best = c;
+			have = true;
+		}
+	};
+	if (in) {
+		for (uint32_t i = threadIdx.x; i < n_in; i += blockDim.x) {
+			if (in[i].have) {
+				offer(in[i].cell);
+			}
+		}
+	} else {
+		for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+			const uint32_t n = out.chunk_count[chunk];
+			const uint32_t *ids = out.ids + (uint64_t)slot * out.slot_stride + (uint64_t)chunk * out.chunk_capacity;
+			for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+				const uint32_t row = ids[i];
+				if (src.valid && !src.valid[row]) {
+					continue; // NULLs take no part
+				}
+				offer(((const uint4 *)src.data)[row]);
+			}
+		}
+	}
+	for (int d = 32; d > 0; d >>= 1) {
+		uint4 o;
+		o.x = __shfl_down(best.x, d, 64);
+		o.y = __shfl_down(best.y, d, 64);
+		o.z = __shfl_down(best.z, d, 64);
+		o.w = __shfl_down(best.w, d, 64);
+		const bool ohave = __shfl_down(have ? 1 : 0, d, 64) != 0;
+		if (ohave && (int)lane + d < 64) {
+			offer(o);
+		}
+	}
+	if (lane == 0) {
+		wave_part[wave].cell = best;
+		wave_part[wave].have = have ? 1u : 0u;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		have = false;
+		for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {
+			if (wave_part[w].have) {
+				offer(wave_part[w].cell);
+			}
+		}
+		StrPartial r;
+		r.cell = best;
+		r.have = have ? 1u : 0u;
+		r.pad[0] = r.pad[1] = r.pad[2] = 0;
+		partials[blockIdx.x] = r;
+	}
+}
+
+static int set_string_heap(polr_ctx *ctx, std::vector<OwnedCol *> cols, uint64_t n_rows, const void *heap_base, uint64_t heap_bytes,
+                           std::vector<void *> &owner) {
+	if (!heap_base || heap_bytes == 0) {
+		return POLR_E_INVALID;
+	}
+	for (OwnedCol *c : cols) {
+		if (c->width != 16) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "a string heap belongs to a column of 16-byte string cells (this one: %u bytes)", c->width);
+		}
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	void *heap = nullptr;
+	unsigned long long *outside = nullptr;
+	HIPCHK(ctx, hipMalloc(&heap, heap_bytes));
+	hipError_t e = hipMalloc((void **)&outside, 8);
+	e = e == hipSuccess ? hipMemcpyAsync(heap, heap_base, heap_bytes, hipMemcpyHostToDevice, ctx->stream) : e;
+	e = e == hipSuccess ? hipMemsetAsync(outside, 0, 8, ctx->stream) : e;
+	if (e == hipSuccess && n_rows) {
+		for (OwnedCol *c : cols) {
+			hipLaunchKernelGGL(polr_rebase_strings_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream,
+			                   (uint4 *)c->data, n_rows, (uint64_t)heap_base, (uint64_t)heap_base + heap_bytes, (uint64_t)heap, outside);
+		}
+	}
+	unsigned long long bad = 0;
+	e = e == hipSuccess ? hipMemcpyAsync(&bad, outside, 8, hipMemcpyDeviceToHost, ctx->stream) : e;
+	e = e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+	if (outside) {
+		hipFree(outside);
+	}
+	if (e != hipSuccess || bad) {
+		hipFree(heap);
+		if (e != hipSuccess) {
+			POLR_FAIL(ctx, POLR_E_HIP, "string heap upload failed: %s", hipGetErrorString(e));
+		}
+		POLR_FAIL(ctx, POLR_E_INVALID, "%llu string cells point outside the heap given for their column", bad);
+	}
+	owner.push_back(heap);
+	return POLR_OK;
+}
+
+extern "C" {
+
+int polr_ht_set_payload_heap(polr_ht *ht, uint32_t payload_col, const void *heap_base, uint64_t heap_bytes) {
+	POLR_ENTRY();
+	if (!ht || payload_col >= ht->n_payload) {
+		return POLR_E_INVALID;
+	}
+	if (ht->kind != KIND_NONE) {
+		// (a finalized perfect table keeps a re-ordered copy of every payload column: rebase before finalizing)
+		POLR_FAIL(ht->ctx, POLR_E_INVALID, "set the string heap of a payload column before the table is finalized");
+	}
+	return set_string_heap(ht->ctx, {&ht->payload[payload_col]}, ht->n_rows_in, heap_base, heap_bytes, ht->heaps);
+}
+
+int polr_pipeline_set_probe_heap(polr_pipeline *p, uint32_t probe_col, const void *heap_base, uint64_t heap_bytes) {
+	POLR_ENTRY();
+	if (!p || probe_col >= p->n_probe_cols) {
+		return POLR_E_INVALID;
+	}
+	if (!p->probe_cols[probe_col].owned) {
+		POLR_FAIL(p->ctx, POLR_E_INVALID, "probe column %u lives in the caller's device memory: its cells must point into HBM already",
+		          probe_col);
+	}
+	return set_string_heap(p->ctx, {&p->probe_cols[probe_col]}, p->n_probe_rows, heap_base, heap_bytes, p->heaps);
+}
+
+int polr_out_aggregate_string(polr_out *o, void *stream, uint32_t fn, int32_t src_join, uint32_t src_col, char *dst,
+                              uint32_t dst_cap, uint32_t *len, uint32_t *is_null) {
+	POLR_ENTRY();
+	if (!o || !len || !is_null || (!dst && dst_cap)) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = o->pipe;
+	polr_ctx *ctx = p->ctx;
+	if (fn != POLR_AGG_MIN && fn != POLR_AGG_MAX) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "string aggregate %u (MIN or MAX)", fn);
+	}
+	const OwnedCol *c;
+	uint32_t slot;
+	if (src_join < 0) {
+		if (src_col >= p->n_probe_cols) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "probe column %u out of range", src_col);
+		}
+		c = &p->probe_cols[src_col];
+		slot = 0;
+	} else {
+		if ((uint32_t)src_join >= p->k || src_col >= p->hts[src_join]->n_payload) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "build column (%d,%u) out of range", src_join, src_col);
+		}
+		const polr_ht *ht = p->hts[src_join];
+		c = ht->kind == KIND_PERFECT ? &ht->pcols[src_col] : &ht->payload[src_col];
+		slot = 1 + (uint32_t)src_join;
+	}
+	if (c->width != 16) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "not a VARCHAR column (%u-byte cells)", c->width);
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	if (!o->stats_valid) {
+		int rc = polr_out_stats(o, stream, nullptr, nullptr, nullptr);
+		if (rc) {
+			return rc;
+		}
+	}
+	*len = 0;
+	*is_null = 1;
+	if (o->n_chunks == 0) {
+		return POLR_OK;
+	}
+	const uint32_t n_blocks = std::max<uint32_t>(1, std::min<uint32_t>(o->n_chunks, (uint32_t)ctx->n_cus * 4));
+	StrPartial *part = nullptr;
+	HIPCHK(ctx, hipMalloc((void **)&part, ((size_t)n_blocks + 1) * sizeof(StrPartial)));
+	DevCol src;
+	src.data = c->data;
+	src.valid = c->valid;
+	src.width = c->width;
+	src.flags = c->flags;
+	hipLaunchKernelGGL(polr_agg_string_kernel, dim3(n_blocks), dim3(256), 0, st, o->dev, o->n_chunks, src, slot,
+	                   fn == POLR_AGG_MAX ? 1 : 0, (const StrPartial *)nullptr, 0u, part);
+	hipLaunchKernelGGL(polr_agg_string_kernel, dim3(1), dim3(256), 0, st, o->dev, 0u, src, slot, fn == POLR_AGG_MAX ? 1 : 0,
+	                   (const StrPartial *)part, n_blocks, part + n_blocks);
+	StrPartial win;
+	hipError_t e = hipMemcpyAsync(&win, part + n_blocks, sizeof(win), hipMemcpyDeviceToHost, st);
+	e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+	if (e == hipSuccess && win.have) {
+		*is_null = 0;
+		*len = win.cell.x;
+		const uint32_t take = std::min<uint32_t>(win.cell.x, dst_cap);
+		if (win.cell.x <= 12) {
+			const uint32_t words[3] = {win.cell.y, win.cell.z, win.cell.w};
+			memcpy(dst, words, take);
+		} else if (take) {
+			e = hipMemcpy(dst, (const void *)(((uint64_t)win.cell.w << 32) | win.cell.z), take, hipMemcpyDeviceToHost);
+		}
+	}
+	hipFree(part);
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "string aggregate failed: %s", hipGetErrorString(e));
+	}
+	return POLR_OK;
+}
+
+} // extern "C"

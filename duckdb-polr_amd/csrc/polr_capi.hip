@@ -791,6 +791,9 @@ void polr_ht_destroy(polr_ht *ht) {
 	for (auto &c : ht->pcols) {
 		free_col(c);
 	}
+	for (void *h : ht->heaps) {
+		hipFree(h);
+	}
 	if (ht->kind == KIND_PERFECT) {
 		if (ht->bits) {
 			hipFree(ht->bits);
@@ -1548,6 +1551,9 @@ void polr_pipeline_destroy(polr_pipeline *p) {
 	hipSetDevice(p->ctx->device);
 	for (auto &c : p->probe_cols) {
 		free_col(c);
+	}
+	for (void *h : p->heaps) {
+		hipFree(h);
 	}
 	if (p->probe_cols_dev) {
 		hipFree(p->probe_cols_dev);

@@ -68,6 +68,7 @@ struct polr_ht {
 	uint32_t *bits = nullptr;
 	uint32_t *idx_row = nullptr;
 	std::vector<OwnedCol> pcols;
+	std::vector<void *> heaps; // string heaps of VARCHAR payload columns (polr_ht_set_payload_heap), owned
 	uint32_t is_dense = 0, has_null = 0;
 	uint64_t device_bytes = 0;
 };
@@ -78,6 +79,7 @@ struct polr_pipeline {
 	uint64_t n_probe_rows = 0;
 	uint64_t n_tuples = 0;
 	std::vector<OwnedCol> probe_cols;
+	std::vector<void *> heaps; // string heaps of VARCHAR probe columns (polr_pipeline_set_probe_heap), owned
 	DevCol *probe_cols_dev = nullptr;
 	uint32_t *sel_dev = nullptr;
 	bool sel_owned = false;

@@ -35,6 +35,7 @@ EXPORTS = [
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
     "polr_ctx_set_pool_tuning", "polr_ctx_get_stream",
+    "polr_ht_set_payload_heap", "polr_pipeline_set_probe_heap", "polr_out_aggregate_string",
 ]
 
 
@@ -135,6 +136,10 @@ def load():
     L.polr_ctx_sync.argtypes = [vp, vp]
     L.polr_ctx_set_pool_tuning.argtypes = [vp, C.POINTER(PoolTuning)]
     L.polr_ctx_get_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.polr_ht_set_payload_heap.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    L.polr_pipeline_set_probe_heap.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    L.polr_out_aggregate_string.argtypes = [vp, vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_char_p, C.c_uint32,
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.polr_ht_upload_rows.argtypes = [vp, vp, u64, u32, vp, vp, vp, u32, u32, P(vp)]
     L.polr_ht_upload_columns.argtypes = [vp, P(Col), u32, P(Col), u32, u64, P(vp)]
     L.polr_ht_finalize_hash.argtypes = [vp, vp]
@@ -208,6 +213,26 @@ def _np_col(arr, valid=None):
 def dev_col(ptr, width, signed=False, valid_ptr=None):
     """column descriptor for memory that is already on the device (e.g. a torch tensor's data_ptr())"""
     return Col(ptr, valid_ptr, width, COL_DEVICE | (COL_SIGNED if signed else 0))
+
+
+def string_cells(values):
+    """VARCHAR column -> (cells, heap): cells = one 16-byte string_t per value (string_type.hpp:23-28: length, then up to 12
+    characters inline, or a 4-byte prefix and a pointer), heap = the bytes the pointers of the long ones point into (a numpy
+    array: keep it alive until the heap has been handed over with set_payload_heap / set_probe_heap).  values: bytes / str."""
+    vals = [v.encode() if isinstance(v, str) else bytes(v) for v in values]
+    heap = np.frombuffer(b"".join(v for v in vals if len(v) > 12) or b"\0", dtype=np.uint8).copy()
+    base = heap.ctypes.data
+    cells = np.zeros((len(vals), 16), dtype=np.uint8)
+    off = 0
+    for i, v in enumerate(vals):
+        cells[i, 0:4] = np.frombuffer(np.uint32(len(v)).tobytes(), dtype=np.uint8)
+        if len(v) <= 12:
+            cells[i, 4:4 + len(v)] = np.frombuffer(v, dtype=np.uint8)
+        else:
+            cells[i, 4:8] = np.frombuffer(v[:4], dtype=np.uint8)
+            cells[i, 8:16] = np.frombuffer(np.uint64(base + off).tobytes(), dtype=np.uint8)
+            off += len(v)
+    return cells.reshape(-1).view("V16"), heap
 
 
 def _col_array(cols):
@@ -284,6 +309,12 @@ class HashTable:
         ctx.check(ctx.L.polr_ht_upload_columns(ctx.h, _col_array(key_cols), len(key_cols), _col_array(payload_cols),
                                                len(payload_cols), n_rows, C.byref(h)))
         return cls(ctx, h)
+
+    def set_payload_heap(self, payload_col, heap):
+        """polr_ht_set_payload_heap: the string heap the cells of payload column `payload_col` point into (before finalize)"""
+        heap = np.ascontiguousarray(heap, dtype=np.uint8)
+        self.ctx.check(self.ctx.L.polr_ht_set_payload_heap(self.h, payload_col, heap.ctypes.data, heap.nbytes))
+        return self
 
     @classmethod
     def from_rows(cls, ctx, rows, n_rows, row_width, col_offset, col_width, col_signed, n_keys, n_payload):
@@ -389,6 +420,11 @@ class Pipeline:
         ctx.check(ctx.L.polr_pipeline_create(ctx.h, _col_array(pc), len(pc), n_probe_rows, jd, self.k,
                                              paths.ctypes.data, self.n_paths, C.byref(h)))
         self.h = h
+
+    def set_probe_heap(self, probe_col, heap):
+        """polr_pipeline_set_probe_heap: the string heap the cells of probe column `probe_col` point into"""
+        heap = np.ascontiguousarray(heap, dtype=np.uint8)
+        self.ctx.check(self.ctx.L.polr_pipeline_set_probe_heap(self.h, probe_col, heap.ctypes.data, heap.nbytes))
 
     def set_selection(self, sel, device=False, n=None):
         if sel is None:
@@ -517,6 +553,18 @@ class Output:
                  for a in range(na)] for g in range(n_groups)]
         counts = [[res[g * na + a].count for a in range(na)] for g in range(n_groups)]
         return vals, counts, dropped.value
+
+    def aggregate_string(self, fn, src_join, src_col, stream=None, cap=4096):
+        """polr_out_aggregate_string: MIN / MAX of a VARCHAR column over the output rows -> bytes, or None (no non-NULL row)"""
+        buf = C.create_string_buffer(cap)
+        n, null = C.c_uint32(), C.c_uint32()
+        self.ctx.check(self.ctx.L.polr_out_aggregate_string(self.h, stream, AGG[fn] if isinstance(fn, str) else fn, src_join,
+                                                            src_col, buf, cap, C.byref(n), C.byref(null)))
+        if null.value:
+            return None
+        if n.value > cap:
+            return self.aggregate_string(fn, src_join, src_col, stream, cap=n.value)
+        return buf.raw[:n.value]
 
     def materialize(self, src_join, src_col, dtype, stream=None):
         n, _, _ = self.stats(stream)
@@ -744,6 +792,11 @@ class Comm:
             pass
 
 
+def string_payload_index(j, col):
+    """payload column number of VARCHAR column `col` of workload join `j` as build_joins uploads it"""
+    return len(j["payload"]) + list(j.get("strings", {}).keys()).index(col)
+
+
 def build_joins(ctx, wl, auto=False):
     """upload + finalize the build sides of a workload dict.  auto=False: the way the reference's planner would
     (perfect table where the plan allows it and the build has no duplicate, hash table otherwise);
@@ -752,8 +805,13 @@ def build_joins(ctx, wl, auto=False):
     joins = []
     for j in wl["joins"]:
         pv = [j.get("payload_valid", {}).get(n) for n in j["payload"].keys()]
-        ht = HashTable.from_columns(ctx, j["keys"], list(j["payload"].values()), key_valid=j.get("key_valid"),
-                                    payload_valid=pv)
+        # VARCHAR payload columns (j["strings"]: name -> bytes per build row) go behind the fixed-width ones, as 16-byte
+        # string_t cells + one heap each (string_payload_index gives their column number)
+        strs = [string_cells(v) for v in j.get("strings", {}).values()]
+        ht = HashTable.from_columns(ctx, j["keys"], list(j["payload"].values()) + [c for c, _h in strs],
+                                    key_valid=j.get("key_valid"), payload_valid=pv + [None] * len(strs))
+        for i, (_c, heap) in enumerate(strs):
+            ht.set_payload_heap(len(j["payload"]) + i, heap)
         done = False
         if auto and len(j["keys"]) == 1 and j["keys"][0].dtype.kind in "iu" and len(j["keys"][0]):
             kv = j.get("key_valid")

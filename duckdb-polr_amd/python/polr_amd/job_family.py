@@ -121,6 +121,24 @@ class Tables:
         self._cols[key] = v
         return v
 
+    def strings(self, table, col, rows=None):
+        """a VARCHAR attribute column (title.title, name.name, movie_info.info ...): one string per row, a pure function
+        of (table, column, row): lengths 3 .. 27 characters, so that both forms of a string_t cell occur (up to 12
+        characters inline, longer ones through the heap); many rows share their first characters, so comparisons have
+        to look past the 4-byte prefix.  rows: the row ids wanted (default: all)"""
+        n = self.rows(table)
+        ids = np.arange(n, dtype=np.int64) if rows is None else np.asarray(rows, dtype=np.int64)
+        h = (_mix32(ids, _salt(table + "." + col)) * (1 << 24)).astype(np.int64)
+        stem = (table[:2] + col[:2]).encode()
+        words = [b"a", b"the", b"of", b"night", b"return", b"story", b"day", b"last"]
+        out = []
+        for i, x in zip(ids.tolist(), h.tolist()):
+            v = stem + b"-" + words[x % 8] + b"-" + str(x % 9973).encode()
+            if x & 0x100:
+                v += b"-" + words[(x >> 9) % 8] + b"-" + str(i).encode()
+            out.append(v)
+        return out
+
 
 def _find(parent, x):
     while parent[x] != x:
@@ -212,7 +230,7 @@ def workload(name, tables, q=None):
         else:
             key_src = [(index_of[src[0]], payload_cols[src[0]].index(src[1]))]
         joins.append({"name": alias, "table": t, "keys": [key], "key_names": [bcol], "payload": payload,
-                      "key_src": key_src, "perfect": None})
+                      "key_src": key_src, "perfect": None, "kept_rows": np.nonzero(keep)[0]})
     # BoundReference index of every join's probe-side condition in the original column layout
     cond_left = []
     for j in joins:
@@ -223,14 +241,28 @@ def workload(name, tables, q=None):
             cond_left.append([len(names) + sum(len(joins[i]["payload"]) for i in range(sj)) + sc])
     wl = {"name": "job_" + name, "probe": {"name": ptable, "cols": probe_cols}, "joins": joins,
           "cond_left_index": cond_left}
+    # the query's select list, MIN(alias.column) ...: the columns of it that this pipeline's tables own, as VARCHAR columns
+    # (wl["select"]: (join index or -1 for the probe table, column name); the strings of the rows kept, in "strings")
+    select = []
+    for alias, col in q.get("select", []):
+        t = q["tables"][alias]
+        if alias == probe:
+            wl["probe"].setdefault("strings", {})[col] = tables.strings(t, col)
+            select.append((-1, col))
+        elif alias in index_of:
+            j = joins[index_of[alias]]
+            if col not in j.setdefault("strings", {}):
+                j["strings"][col] = tables.strings(t, col, rows=j["kept_rows"])
+            select.append((index_of[alias], col))
+    wl["select"] = select
     if flt:
         wl["probe"]["filter"] = flt
         wl["probe"]["filter_sel"] = np.nonzero(probe_cols["f"] < flt[0][2])[0].astype(np.uint32)
-    wl["ref"] = _reference_form(probe, probe_cols, flt, order, joins)
+    wl["ref"] = _reference_form(probe, probe_cols, flt, order, joins, select, wl["probe"].get("strings"))
     return wl
 
 
-def _reference_form(probe, probe_cols, flt, order, joins):
+def _reference_form(probe, probe_cols, flt, order, joins, select=(), probe_strings=None):
     """how the same pipeline reads for the reference (as SQL over uploaded tables): one table per alias -- the probe table with its
     filter column, every build side with the rows its filters keep -- and the joins as a left-deep chain in pipeline order,
     pinned with `SET disabled_optimizers TO 'join_order,...'`: the plan the reference executes is then one pipeline whose
@@ -243,17 +275,26 @@ def _reference_form(probe, probe_cols, flt, order, joins):
         return "%s__%s" % (alias, col)
 
     tables = {tname(probe): {cname(probe, c): a for c, a in probe_cols.items()}}
+    for c, vals in (probe_strings or {}).items():
+        tables[tname(probe)][cname(probe, c)] = vals
     sql = "SELECT COUNT(*) FROM %s" % tname(probe)
     for (alias, bcol, src), j in zip(order, joins):
         cols = {cname(alias, bcol): j["keys"][0]}
         for c, a in j["payload"].items():
             if c != bcol:
                 cols[cname(alias, c)] = a
+        for c, vals in j.get("strings", {}).items():
+            cols[cname(alias, c)] = vals
         tables[tname(alias)] = cols
         sql += " JOIN %s ON %s = %s" % (tname(alias), cname(src[0], src[1]), cname(alias, bcol))
     if flt:
         sql += " WHERE " + " AND ".join("%s %s %d" % (cname(probe, c), op, const) for c, op, const in flt)
     # (statistics propagation is switched off with the join order optimizer: on a reduced instance it finds build sides
     # whose key ranges miss the probe side's, and replaces such a join -- and with it the pipeline -- by an empty result)
-    return {"tables": tables, "pk": {}, "query": sql,
-            "settings": ["SET disabled_optimizers TO 'join_order,statistics_propagation'"]}
+    out = {"tables": tables, "pk": {}, "query": sql,
+           "settings": ["SET disabled_optimizers TO 'join_order,statistics_propagation'"]}
+    if select:
+        aliases = [probe] + [a for a, _b, _s in order]
+        out["query_select"] = sql.replace("SELECT COUNT(*)", "SELECT " + ", ".join(
+            "MIN(%s)" % cname(aliases[1 + sj], c) for sj, c in select))
+    return out

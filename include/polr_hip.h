@@ -327,6 +327,20 @@ typedef struct polr_group_key {
 int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_group_key *keys, uint32_t n_keys,
                                const polr_agg_spec *specs, uint32_t n_aggs, polr_agg_value *results,
                                uint64_t n_groups, uint64_t *n_dropped);
+/* ---- VARCHAR columns and their sink (every JOB query ends in MIN of a VARCHAR: benchmark/imdb_plan_cost/queries/18a.sql:1-3) --------
+ * A width-16 column holds string_t cells (src/include/duckdb/common/types/string_type.hpp:23-28: 4-byte length; up to 12
+ * characters inline; longer: a 4-byte prefix and an 8-byte pointer into a string heap).  RowOperations::Gather copies such
+ * cells as they are, the pointer staying into the table's heap (row_gather.cpp:47-86).  A column with non-inlined strings
+ * needs that heap on the device: these calls copy the `heap_bytes` bytes at `heap_base` (the address range the uploaded
+ * cells' pointers lie in) into HBM and rebase the pointers of the column's cells; owned by the table / pipeline. */
+int polr_ht_set_payload_heap(polr_ht *ht, uint32_t payload_col, const void *heap_base, uint64_t heap_bytes);
+int polr_pipeline_set_probe_heap(polr_pipeline *p, uint32_t probe_col, const void *heap_base, uint64_t heap_bytes);
+/* MIN / MAX (fn = POLR_AGG_MIN / POLR_AGG_MAX) of a VARCHAR column over the pipeline's output rows, reduced on the
+ * device (src/function/aggregate/distributive/minmax.cpp over string_t: bytes compared as unsigned, a proper prefix
+ * sorts first; NULLs take no part).  The winning string's bytes go to dst (at most dst_cap of them), *len = its whole
+ * length; *is_null = 1 when no row had a non-NULL value. */
+int polr_out_aggregate_string(polr_out *o, void *stream, uint32_t fn, int32_t src_join, uint32_t src_col, char *dst,
+                              uint32_t dst_cap, uint32_t *len, uint32_t *is_null);
 void polr_out_destroy(polr_out *o);
 
 /* ---------------------------------------------------------------------------------------------

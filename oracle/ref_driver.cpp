@@ -9,6 +9,7 @@
 //
 // Script language (one command per line, '#' comments):
 //   table <name> <nrows>                       start a table definition
+//   col <name> VARCHAR <file>                    strings, each a little-endian u32 length followed by its bytes
 //   col <name> <SQLTYPE> <file> [pk]            raw little-endian column file (i32/u32/i64/u16/...); pk: the column is the
 //                                               table's PRIMARY KEY (what benchmark/ssb-skew/init/load.sql declares for the
 //                                               dimension keys; SelSampleEnumeration reads the constraint)
@@ -39,6 +40,7 @@ struct ColDef {
 	std::string name, type, file;
 	bool pk = false;
 	std::vector<char> data;
+	std::vector<size_t> offsets; // VARCHAR: where each row's {length, bytes} record starts
 	size_t width;
 };
 
@@ -75,11 +77,30 @@ static void LoadTable(Connection &con, const std::string &name, idx_t nrows, std
 		Fail(ddl, r->GetError());
 	}
 	for (auto &c : cols) {
-		c.width = TypeWidth(c.type);
 		std::ifstream f(c.file, std::ios::binary);
 		if (!f) {
 			Fail("open " + c.file, "cannot open");
 		}
+		if (c.type == "VARCHAR") {
+			c.width = 0;
+			c.data.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+			c.offsets.clear();
+			size_t at = 0;
+			for (idx_t row = 0; row < nrows; row++) {
+				if (at + 4 > c.data.size()) {
+					Fail("read " + c.file, "short file");
+				}
+				uint32_t len;
+				memcpy(&len, c.data.data() + at, 4);
+				c.offsets.push_back(at);
+				at += 4 + len;
+			}
+			if (at > c.data.size()) {
+				Fail("read " + c.file, "short file");
+			}
+			continue;
+		}
+		c.width = TypeWidth(c.type);
 		c.data.resize(nrows * c.width);
 		f.read(c.data.data(), (std::streamsize)c.data.size());
 		if ((idx_t)f.gcount() != nrows * c.width) {
@@ -90,6 +111,12 @@ static void LoadTable(Connection &con, const std::string &name, idx_t nrows, std
 	for (idx_t row = 0; row < nrows; row++) {
 		appender.BeginRow();
 		for (auto &c : cols) {
+			if (c.type == "VARCHAR") {
+				uint32_t len;
+				memcpy(&len, c.data.data() + c.offsets[row], 4);
+				appender.Append(Value(std::string(c.data.data() + c.offsets[row] + 4, len)));
+				continue;
+			}
 			const char *p = c.data.data() + row * c.width;
 			if (c.type == "INTEGER") {
 				appender.Append<int32_t>(*(const int32_t *)p);

@@ -25,6 +25,13 @@ def table_lines(workdir, name, cols, pk=None):
     lines = ["table %s %d" % (name, n)]
     for cname, arr in cols.items():
         path = os.path.join(workdir, "%s.%s.bin" % (name, cname))
+        if isinstance(arr, (list, tuple)):  # a VARCHAR column: bytes / str per row
+            with open(path, "wb") as f:
+                for v in arr:
+                    v = v.encode() if isinstance(v, str) else bytes(v)
+                    f.write(np.uint32(len(v)).tobytes() + v)
+            lines.append("col %s VARCHAR %s" % (cname, path))
+            continue
         np.ascontiguousarray(arr).tofile(path)
         lines.append("col %s %s %s%s" % (cname, SQLTYPE[str(arr.dtype)], path, " pk" if cname == pk else ""))
     lines.append("endtable")

@@ -40,6 +40,48 @@ def oracle_run(wl, paths, routing):
                                    collect_output=False, sel=sel, chunk_offsets=offs)
 
 
+def select_run(ref, settings):
+    """the reference on the pipeline's MIN(...) select list: one row of strings (None = SQL NULL: no row survived)"""
+    import subprocess
+    import tempfile
+    from oracle import ref_run
+    workdir = tempfile.mkdtemp(prefix="polr_golden_")
+    lines = []
+    for name, cols in ref["tables"].items():
+        lines += ref_run.table_lines(workdir, name, cols, pk=ref["pk"].get(name))
+    lines += ["sql SET threads TO 1"] + ["sql " + s for s in ref["settings"]] + ["sql " + s for s in settings]
+    lines.append("query q " + ref["query_select"])
+    open(workdir + "/s.txt", "w").write("\n".join(lines) + "\n")
+    p = subprocess.run([ref_run.DRIVER, workdir + "/s.txt", workdir + "/out"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    row = open(workdir + "/out/q.csv").read().split("\n")[1].split(",")
+    return [None if x == "NULL" else x for x in row]
+
+
+def oracle_select(wl, paths):
+    """MIN of every select-list column over the oracle's output rows (bytes order: what the reference's string comparison
+    is for these ASCII values)"""
+    res = oracle_run_rows(wl, paths)
+    rows = res["out_rows"]
+    out = []
+    for sj, col in wl["select"]:
+        vals = wl["probe"]["strings"][col] if sj < 0 else wl["joins"][sj]["strings"][col]
+        ids = rows[:, 0] if sj < 0 else rows[:, 1 + sj]
+        out.append(min((vals[i] for i in ids.tolist()), default=None))
+    return [None if v is None else v.decode() for v in out]
+
+
+def oracle_run_rows(wl, paths):
+    import bench
+    oj = [common.orc.JoinSpec(common.orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"]) for j in wl["joins"]]
+    sel = wl["probe"].get("filter_sel")
+    offs = None
+    if sel is not None:
+        offs = bench.chunk_offsets_for(sel, len(next(iter(wl["probe"]["cols"].values()))), 1024)
+    return common.orc.run_pipeline(list(wl["probe"]["cols"].values()), oj, paths[:1], routing="default_path", caching=False,
+                                   collect_output=True, sel=sel, chunk_offsets=offs)
+
+
 def matrix_sha(m):
     return hashlib.sha1(np.ascontiguousarray(m, dtype=np.uint64).tobytes()).hexdigest()
 
@@ -69,7 +111,13 @@ def main():
         rounds = g.parse_rounds(log2)
         res2 = oracle_run(wl, paths, "adaptive_reinit")
         assert answer2 == answer and list(res2["intermediates_per_round"]) == rounds and res2["num_intermediates"] == intms2, name
-        gold["queries"][name] = {"joins": [j["name"] for j in wl["joins"]], "n_join_orders": int(want.shape[1]),
+        # the query's own sink: MIN(<varchar>) of every select-list column this pipeline's tables own
+        select_min = None
+        if wl["select"]:
+            select_min = select_run(ref, base + ["SET multiplexer_routing TO 'adaptive_reinit'"])
+            assert select_min == oracle_select(wl, paths), (name, select_min, oracle_select(wl, paths))
+        gold["queries"][name] = {"select": [[sj, c] for sj, c in wl["select"]], "select_min": select_min,
+                                 "joins": [j["name"] for j in wl["joins"]], "n_join_orders": int(want.shape[1]),
                                  "n_chunks": int(want.shape[0]), "count_star": int(answer),
                                  "alternate_sums": want.sum(axis=0).tolist(), "alternate_sha1": matrix_sha(want),
                                  "alternate_intms": int(intms), "adaptive_rounds": rounds, "adaptive_intms": int(intms2),

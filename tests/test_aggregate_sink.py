@@ -345,3 +345,49 @@ def test_device_q41_as_shipped_on_the_flat_pipeline(gpu_ctx, n_exec):
     for m_ in mpxs:
         m_.close()
     pipe.close()
+
+
+@pytest.mark.gpu
+def test_string_min_max_over_inline_and_heap_cells(gpu_ctx):
+    """polr_out_aggregate_string over string_t cells: strings of 0 .. 40 bytes (inline up to 12, heap beyond), many sharing
+    their first 4 / 12 / 20 bytes, bytes above 0x7F (compared unsigned), proper prefixes (the shorter first), NULL cells (take
+    no part), probe-side and build-side columns; MIN and MAX against python's bytes order (the reference's string order:
+    memcmp over the common length, then the length -- src/include/duckdb/common/types/string_type.hpp)"""
+    from polr_amd import capi
+    rng = np.random.default_rng(11)
+    stems = [b"", b"a", b"abcd", b"abcdefghijkl", b"abcdefghijklmnopqrst", b"abce", b"\xc3\xa9t\xc3\xa9", b"abcdefghijklm"]
+    n_build = 3000
+
+    def rand_str():
+        s_ = stems[rng.integers(0, len(stems))]
+        return s_ + bytes(rng.integers(97, 100, rng.integers(0, 21)).astype(np.uint8))
+
+    bvals = [rand_str() for _ in range(n_build)]
+    bkeys = rng.permutation(np.arange(1, n_build + 1, dtype=np.int32))
+    bvalid = (rng.random(n_build) > 0.2).astype(np.uint8)
+    cells, heap = capi.string_cells(bvals)
+    ht = capi.HashTable.from_columns(gpu_ctx, [bkeys], [cells], payload_valid=[bvalid])
+    ht.set_payload_heap(0, heap)
+    ht.finalize_hash()
+    n = 50_000
+    pk = rng.integers(1, 2 * n_build, n).astype(np.int32)
+    pvals = [rand_str() for _ in range(n)]
+    pcells, pheap = capi.string_cells(pvals)
+    pipe = capi.Pipeline(gpu_ctx, [pk, pcells], n, [(ht, [(-1, 0)])], [[0]])
+    pipe.set_probe_heap(1, pheap)
+    out = capi.Output(pipe, 1024, 8192)
+    pipe.probe_rounds([(0, n, 0, 1)], out=out)
+    ids = out.fetch_ids()
+    assert len(ids) > 10_000
+    build_seen = [bvals[i] for i in ids[:, 1].tolist() if bvalid[i]]
+    probe_seen = [pvals[i] for i in ids[:, 0].tolist()]
+    assert out.aggregate_string("min", 0, 0) == min(build_seen) and out.aggregate_string("max", 0, 0) == max(build_seen)
+    assert out.aggregate_string("min", -1, 1) == min(probe_seen) and out.aggregate_string("max", -1, 1) == max(probe_seen)
+    # no row at all: SQL NULL
+    out2 = capi.Output(pipe, 1024, 64)
+    pipe.probe_rounds([(0, 0, 0, 1)], out=out2)
+    assert out2.aggregate_string("min", 0, 0) is None
+    with pytest.raises(capi.PolrError):
+        out.aggregate_string("min", -1, 0)  # not a VARCHAR column
+    pipe.close()
+    ht.close()

@@ -68,6 +68,17 @@ def _oracle(wl, paths, routing):
                             collect_output=False, sel=sel, chunk_offsets=offs)
 
 
+def _oracle_rows(wl, paths):
+    oj = [orc.JoinSpec(orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"]) for j in wl["joins"]]
+    sel = wl["probe"].get("filter_sel")
+    offs = None
+    if sel is not None:
+        import bench
+        offs = bench.chunk_offsets_for(sel, len(next(iter(wl["probe"]["cols"].values()))), 1024)
+    return orc.run_pipeline(list(wl["probe"]["cols"].values()), oj, paths[:1], routing="default_path", caching=False,
+                            collect_output=True, sel=sel, chunk_offsets=offs)["out_rows"]
+
+
 @pytest.mark.parametrize("name", sorted(SHAPES))
 def test_oracle_matches_the_reference_on_every_query(name):
     """tests/golden/job_family.json (tests/golden/make_golden_job.py): the reference itself ran every one of the 113
@@ -89,6 +100,17 @@ def test_oracle_matches_the_reference_on_every_query(name):
     res = _oracle(wl, paths, "adaptive_reinit")
     assert list(res["intermediates_per_round"]) == g["adaptive_rounds"] and res["num_intermediates"] == g["adaptive_intms"]
     assert res["num_output_rows"] == g["count_star"]
+    # the query's own sink: MIN(<varchar>) per select-list column, against the reference's answer
+    assert [[sj, c] for sj, c in wl["select"]] == g["select"]
+    if wl["select"]:
+        rows = _oracle_rows(wl, paths)
+        got = []
+        for sj, col in wl["select"]:
+            vals = wl["probe"]["strings"][col] if sj < 0 else wl["joins"][sj]["strings"][col]
+            ids = rows[:, 0] if sj < 0 else rows[:, 1 + sj]
+            m = min((vals[i] for i in ids.tolist()), default=None)
+            got.append(None if m is None else m.decode())
+        assert got == g["select_min"]
 
 
 @pytest.mark.gpu
@@ -105,7 +127,11 @@ def test_device_matches_the_reference_on_every_query(gpu_ctx):
         paths = _each_last_once(wl)
         joins = capi.build_joins(gpu_ctx, wl, auto=True)
         cols = list(wl["probe"]["cols"].values())
-        pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, paths)
+        # VARCHAR columns of the probe table that the select list names: string_t cells behind the key columns + their heap
+        pstr = [capi.string_cells(v) for v in wl["probe"].get("strings", {}).values()]
+        pipe = capi.Pipeline(gpu_ctx, cols + [c for c, _h in pstr], len(cols[0]), joins, paths)
+        for i, (_c, heap) in enumerate(pstr):
+            pipe.set_probe_heap(len(cols) + i, heap)
         flt = wl["probe"].get("filter")
         if flt:
             _n, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt])
@@ -130,6 +156,26 @@ def test_device_matches_the_reference_on_every_query(gpu_ctx):
                 assert st["num_intermediates"] == g["adaptive_intms"], name
                 assert sum(st["stage_out"][p][k - 1] for p in range(P)) == g["count_star"], name
             mpx.close()
+        if wl["select"]:
+            # the query's own sink on the device: a materialising adaptive run, then MIN over the VARCHAR column's string_t
+            # cells (inline and heap strings) by output row id -- polr_out_aggregate_string
+            out = capi.Output(pipe, 1024, 16384)
+            mpx = capi.DeviceMultiplexer(pipe, "adaptive_reinit")
+            if flt:
+                mpx.use_scan_chunks()
+            capi.run_resident([mpx], [(0, n_chunks)], out=out, reset=True, finish=True)
+            mpx.finish()
+            got = []
+            for sj, col in wl["select"]:
+                if sj < 0:
+                    v = out.aggregate_string("min", -1, len(cols) + list(wl["probe"]["strings"].keys()).index(col))
+                else:
+                    v = out.aggregate_string("min", sj, capi.string_payload_index(wl["joins"][sj], col))
+                got.append(None if v is None else v.decode())
+            assert got == g["select_min"], (name, got, g["select_min"])
+            assert out.stats()[0] == g["count_star"], name
+            mpx.close()
+            out.close()
         pipe.close()
         for ht, _ in joins:
             ht.close()

@@ -2,7 +2,8 @@
 """tools/make_job_shapes.py -- BUILD CONTAINER ONLY.  Reads the 113 JOB queries of the reference
 (benchmark/imdb_plan_cost/queries/*.sql, the SQL behind benchmark/imdb/*.benchmark) AS DATA and writes the join
 *shapes* bench.py's config 4 needs to duckdb-polr_amd/python/polr_amd/job_shapes.json: per query the tables, the
-equi-join graph (as column equivalence classes) and, per table, how many filter predicates of which kind it carries.
+equi-join graph (as column equivalence classes), per table how many filter predicates of which kind it carries, and which
+columns the query's MIN(...) select list names.
 No SQL text, literal or identifier beyond table / column names is kept."""
 import glob
 import json
@@ -81,7 +82,9 @@ def parse(sql):
         kind = classify(pred)
         for a in aliases:
             filters[a].append(kind)
-    return {"tables": tables, "joins": joins, "filters": {a: f for a, f in filters.items() if f}}
+    # the select list: every JOB query returns MIN(alias.column) of a few (mostly VARCHAR) columns
+    select = [[a, c] for a, c in re.findall(r"\bMIN\s*\(\s*(\w+)\.(\w+)\s*\)", sql[:m.start()], flags=re.I) if a in tables]
+    return {"tables": tables, "joins": joins, "filters": {a: f for a, f in filters.items() if f}, "select": select}
 
 
 def main():
