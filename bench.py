@@ -57,6 +57,20 @@ def ref_capacity(n):
     return p
 
 
+def find_pmc_summary(sig):
+    """The committed PMC summary (profiles/r??_*_pmc_summary.json, newest round first) of exactly this command, if any:
+    (summary, file name).  Written by tools/publish_profiles_r03.py from separate rocprofv3 --pmc passes."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("workload_signature") == sig and pmc.get("traffic_bytes_per_launch_corrected"):
+            return pmc, os.path.basename(f)
+    return None, None
+
+
 def algorithmic_bytes(joins_info, paths, tuples_per_path, stage_out):
     """per input tuple of join j:  chained  K + 8 + c(1+K+8) + m(P+4+P),
     perfect  K + 1 + m(4+4);  c = m + n_build/capacity (matching rows + expected bucket collisions at
@@ -616,7 +630,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                     "traffic": None,
                     "traffic_note": "not measured inside bench.py (PMC passes are separate rocprofv3 runs: profiles/) and "
                                     "no committed PMC pass matches this command",
-                    "kernel": "polr_pool_flat_kernel" if info.get("flat") else "polr_pool_kernel",
+                    "kernel": "polr_pool_flat_kernel" if info.get("flat") else "polr_pool_gen_kernel",
                     "algorithmic_bytes_per_step": round(alg),
                     "algorithmic_bytes_per_tuple": round(alg / max(n_tuples, 1), 3),
                     "kernel_ms_per_step": round(kernel_ms / steps, 4),
@@ -631,16 +645,14 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                             "time includes the device-side waits between dependent routing rounds)"}
             sig = {"workload": name, "scale": float(scale), "routing": routing, "join_enumerator": enumerator,
                    "max_join_orders": int(args.max_join_orders), "executors_per_gpu": int(E), "n_gpus": int(world)}
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_ssb_sf100_pmc_summary.json")))
-            except (OSError, ValueError):
-                pmc = None
-            if pmc and pmc.get("workload_signature") == sig and not args.morsels and not device_scan:
+            roof["pmc_signature"] = sig
+            pmc, pmc_file = find_pmc_summary(sig)
+            if pmc and not args.morsels and not device_scan:
                 # REPLAYED, not measured in this run: HBM bytes per launch of the same command's separate rocprofv3
                 # --pmc passes (FETCH_SIZE, WRITE_SIZE), FETCH_SIZE corrected as calibrated for this kernel's access
                 # patterns on gfx950 (profiles/r02_fetch_size_calibration.json)
                 roof["traffic"] = int(pmc["traffic_bytes_per_launch_corrected"])
-                roof["traffic_source"] = "replayed from profiles/r02_ssb_sf100_pmc_summary.json"
+                roof["traffic_source"] = "replayed from profiles/" + pmc_file
                 roof["traffic_note"] = pmc["traffic_note"]
         cpu = None
         if with_cpu:
@@ -734,6 +746,69 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
     del tens
     torch.cuda.empty_cache()
     return rec
+
+
+def cpu_baseline_job_full(cases, args, budget_s=40.0, cap_tuples=6_000_000):
+    """job_full: a BOUNDED sample of the family through the reference itself -- the pipelines of this rank in order, those
+    with at most `cap_tuples` probe tuples, until about `budget_s` seconds of wall clock are spent (table load included) --
+    each at one thread and at 16 (the best valid count on the other workloads); value = sum of their probe tuples / sum of
+    their best valid pipeline times.  Without oracle/_ref: the oracle restatement on the first pipelines (kind "port")."""
+    from oracle import ref_run
+    if ref_run.available() and all("ref" in c["wl"] for c in cases[:1]):
+        t_start = time.time()
+        done, secs, used, threads_used, bad = 0, 0.0, [], {}, []
+        ladder = sorted({1, min(16, os.cpu_count() or 1)})
+        for c in cases:
+            if time.time() - t_start > budget_s:
+                break
+            if c["n_tuples"] > cap_tuples or "ref" not in c["wl"]:
+                continue
+            ref = c["wl"]["ref"]
+            settings = list(ref["settings"]) + ["SET multiplexer_routing TO '%s'" % args.routing,
+                                                "SET join_enumerator TO 'each_last_once'"]
+            try:
+                runs = reference_runs(ref["tables"], ref.get("pk", {}), ref["query"], settings, c["n_tuples"], repeat=3,
+                                      threads=ladder)
+            except Exception as e:  # (one plan the reference cannot run does not take the sample down)
+                bad.append("%s: %s" % (c["name"], str(e)[-120:]))
+                continue
+            best, _detail = pick_baseline(runs, c["n_tuples"])
+            if not best:
+                continue
+            done += c["n_tuples"]
+            secs += c["n_tuples"] / best[0]
+            used.append(c["name"])
+            threads_used[str(best[1])] = threads_used.get(str(best[1]), 0) + 1
+        if done:
+            return {"value": round(done / secs, 1), "unit": "probe-tuples/s", "cores": max(int(t) for t in threads_used),
+                    "kind": "reference",
+                    "sample": "%d of this rank's %d pipelines (in order, those of at most %d probe tuples, until %.0f s of wall "
+                              "clock incl. loading their tables): %s -- the reference's POLAR pipeline on the same synthetic "
+                              "tables, each at threads %s, median of 3 runs, the faster run with the single-threaded COUNT(*) "
+                              "counts; value = their probe tuples / their pipeline times"
+                              % (len(used), len(cases), cap_tuples, budget_s, ", ".join(used), ladder),
+                    "best_thread_count_histogram": threads_used, "pipelines_the_reference_failed_on": bad or None}
+    from oracle import polr_oracle as orc
+    done, secs = 0, 0.0
+    cap = 300_000
+    for c in cases[:4]:
+        wl = c["wl"]
+        oj = [orc.JoinSpec(orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"]) for j in wl["joins"]]
+        sel = wl["probe"].get("filter_sel")
+        pc = list(wl["probe"]["cols"].values())
+        if sel is not None:
+            sel = sel[:cap]
+            n_s = len(sel)
+        else:
+            pc = [a[:cap] for a in pc]
+            n_s = len(pc[0])
+        t_c = time.time()
+        orc.run_pipeline(pc, oj, c["paths"], routing=args.routing, collect_output=False, sel=sel)
+        secs += time.time() - t_c
+        done += n_s
+    return {"value": round(done / secs, 1), "unit": "probe-tuples/s", "cores": 1, "kind": "port",
+            "sample": "the first %d probe tuples of the first %d pipelines of rank 0 through the oracle restatement, single "
+                      "thread (oracle/_ref is not built here)" % (cap, min(4, len(cases)))}
 
 
 def run_job_full(args, env, steps, warmup, with_cpu):
@@ -869,36 +944,14 @@ def run_job_full(args, env, steps, warmup, with_cpu):
             sec = kernel_ms / 1e3 / steps
             roof = {"bound": "hbm", "achieved": round(alg / sec / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "polr_pool_kernel / polr_pool_flat_kernel (one launch per pipeline and pass)",
+                    "kernel": "polr_pool_gen_kernel / polr_pool_flat_kernel (one launch per pipeline and pass)",
                     "algorithmic_bytes_per_step": round(alg), "kernel_ms_per_step": round(kernel_ms / steps, 4),
                     "launches_per_step": launches / steps,
                     "note": "rank 0's pipelines; algorithmic bytes per SURVEY.md 8(d) summed over them"}
         cpu = None
         if with_cpu:
             try:
-                from oracle import polr_oracle as orc
-                done, secs = 0, 0.0
-                for c in cases[:4]:
-                    wl = c["wl"]
-                    oj = [orc.JoinSpec(orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"])
-                          for j in wl["joins"]]
-                    sel = wl["probe"].get("filter_sel")
-                    pc = list(wl["probe"]["cols"].values())
-                    cap = 300_000
-                    if sel is not None:
-                        sel = sel[:cap]
-                        n_s = len(sel)
-                    else:
-                        pc = [a[:cap] for a in pc]
-                        n_s = len(pc[0])
-                    t_c = time.time()
-                    orc.run_pipeline(pc, oj, c["paths"], routing=args.routing, collect_output=False, sel=sel)
-                    secs += time.time() - t_c
-                    done += n_s
-                cpu = {"value": round(done / secs, 1), "unit": "probe-tuples/s", "cores": 1, "kind": "port",
-                       "sample": "the first %d probe tuples of the first %d pipelines of rank 0 through the oracle "
-                                 "restatement, single thread (the reference cannot run the synthetic JOB-shaped family: "
-                                 "its queries exist as shapes only)" % (cap, min(4, len(cases)))}
+                cpu = cpu_baseline_job_full(cases, args)
             except Exception as e:
                 cpu = {"value": None, "error": str(e)[-600:]}
         # which pipelines carry the pass: the ten longest, with what their joins produced (all join orders together)
@@ -1206,7 +1259,7 @@ def main():
     for env_name, field in (("POLR_POOL_SHARE", "device_share"), ("POLR_POOL_UNITS_X", "units_x"),
                             ("POLR_POOL_HI_UNIT", "hi_unit"), ("POLR_POOL_HI_LOTTERY", "hi_lottery"),
                             ("POLR_POOL_HI_TUPLES", "hi_tuples"), ("POLR_POOL_IDLE_SLEEP", "idle_sleep"),
-                            ("POLR_POOL_WATCHDOG_US", "watchdog_us")):
+                            ("POLR_POOL_WATCHDOG_US", "watchdog_us"), ("POLR_POOL_SHARE_AFTER", "share_after")):
         if os.environ.get(env_name):
             knobs[field] = int(os.environ[env_name])
     if knobs:

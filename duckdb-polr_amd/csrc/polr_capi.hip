@@ -128,8 +128,8 @@ int polr_ctx_set_pool_tuning(polr_ctx *ctx, const polr_pool_tuning *t) {
 	if (t->idle_sleep && t->idle_sleep != 16 && t->idle_sleep != 64) {
 		POLR_FAIL(ctx, POLR_E_INVALID, "idle_sleep %u: 16 or 64", t->idle_sleep);
 	}
-	if (t->reserved) {
-		return POLR_E_INVALID;
+	if (t->share_after && t->share_after != 0xFFFFFFFFu && (t->share_after < 16 || t->share_after > 65535)) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "share_after %u: 16..65535 steps, or 0xFFFFFFFF for never", t->share_after);
 	}
 	ctx->tuning = *t;
 	return POLR_OK;

@@ -210,6 +210,10 @@ __device__ __forceinline__ void flat_lookup(const FlatStage &s, const POLR_LDS u
 	}
 }
 
+#ifndef POLR_FLAT_EMIT
+#define POLR_FLAT_EMIT 0 // 1: the build whose last join can write row ids (a counting run never pays for that code:
+                         // inlined at every place a stage emits it cost the SF100 headline 6 % -- 96 more spilled SGPRs)
+#endif
 #define FLAT_NO_CHUNK 0xFFFFFFFFu
 // the tuples that survived the last join leave as row ids (emitting runs): the probe row, and for every join the build id
 // its key stands for -- every join of an emitting flat pipeline is a perfect table, whose build id IS key - min
@@ -279,12 +283,14 @@ template <int K, int POS, int F>
 __device__ __forceinline__ void flat_emit(FlatCtx<K> &c, const uint32_t (&pos)[F], const bool (&hit)[F]) {
 	const bool last = POS + 1 >= K || POS + 1 == (int)c.k;
 	uint32_t total = 0;
+#if POLR_FLAT_EMIT
 	if (last && c.emit) {
 #pragma unroll
 		for (int i = 0; i < F; i++) {
 			flat_out_write<K>(c, pos[i], hit[i]);
 		}
 	}
+#endif
 	if constexpr (POS + 1 < K) {
 		POLR_LDS uint16_t *qq = c.q + flat_qoff<K>(POS + 1);
 		uint32_t qs = c.qsize[POS + 1];

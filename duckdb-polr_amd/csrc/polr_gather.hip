@@ -136,9 +136,13 @@ hipError_t polr_launch_poolg_kernelx(uint32_t W, uint32_t k, uint32_t n_blocks, 
 	size_t polr_pool_flat_lds_bytes_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                           \
 	size_t polr_pool_flat_wave_bytes_k##KK();                                                                         \
 	int polr_pool_flat_occupancy_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                              \
+	int polr_pool_flat_occupancy_e_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                            \
 	hipError_t polr_launch_pool_flat_kernel_k##KK(uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords, \
 	                                              hipStream_t stream, const DevPipeline *pipe,                        \
-	                                              const ResidentExec *execs, PoolRun *run, DevOut out);
+	                                              const ResidentExec *execs, PoolRun *run, DevOut out);               \
+	hipError_t polr_launch_pool_flat_kernel_e_k##KK(uint32_t n_blocks, uint32_t waves_per_block,                      \
+	                                                uint32_t table_dwords, hipStream_t stream, const DevPipeline *pipe, \
+	                                                const ResidentExec *execs, PoolRun *run, DevOut out);
 DECL_POOL_K(2)
 DECL_POOL_K(4)
 DECL_POOL_K(6)
@@ -238,14 +242,25 @@ extern "C++" size_t polr_pool_flat_wave_bytes(uint32_t k) {
 	            polr_pool_flat_wave_bytes_k8())
 }
 
-extern "C++" int polr_pool_flat_occupancy(uint32_t k, uint32_t wpb, uint32_t table_dwords) {
+extern "C++" int polr_pool_flat_occupancy(uint32_t k, uint32_t wpb, uint32_t table_dwords, bool emit) {
+	if (emit) {
+		POOL_SWITCH(k, polr_pool_flat_occupancy_e_k2(wpb, table_dwords), polr_pool_flat_occupancy_e_k4(wpb, table_dwords),
+		            polr_pool_flat_occupancy_e_k6(wpb, table_dwords), polr_pool_flat_occupancy_e_k8(wpb, table_dwords))
+	}
 	POOL_SWITCH(k, polr_pool_flat_occupancy_k2(wpb, table_dwords), polr_pool_flat_occupancy_k4(wpb, table_dwords),
 	            polr_pool_flat_occupancy_k6(wpb, table_dwords), polr_pool_flat_occupancy_k8(wpb, table_dwords))
 }
 
+// emit: the run may write row ids (the build of the flat kernel that carries that code)
 extern "C++" hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t wpb, uint32_t table_dwords,
                                                      hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                                     PoolRun *run, DevOut out) {
+                                                     PoolRun *run, DevOut out, bool emit) {
+	if (emit) {
+		POOL_SWITCH(k, polr_launch_pool_flat_kernel_e_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
+		            polr_launch_pool_flat_kernel_e_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
+		            polr_launch_pool_flat_kernel_e_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
+		            polr_launch_pool_flat_kernel_e_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out))
+	}
 	POOL_SWITCH(k, polr_launch_pool_flat_kernel_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
 	            polr_launch_pool_flat_kernel_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
 	            polr_launch_pool_flat_kernel_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),

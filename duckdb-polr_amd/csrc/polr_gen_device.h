@@ -18,8 +18,10 @@
 //     begins.  The whole probe side is a few KB of code.
 //   * every access names its address space (global / LDS / constant): no FLAT instruction, so LDS traffic and the
 //     key / table loads in flight wait on separate counters.
-//   * a step takes up to 256 tuples, four per lane: the four (sel ->) key -> slot-group chains of a lane are in
-//     flight together, at every stage (round 2: stage 0 and sometimes the last one).
+//   * a step takes up to 64 x GEN_F tuples, GEN_F per lane: the (sel ->) key -> slot-group chains of a lane are in
+//     flight together, at every stage (round 2: stage 0 and sometimes the last one).  The library is built with
+//     GEN_F = 2 (Makefile: GENF): measured against 1 and 4 on the JOB 18a / JOB-light shapes and the 113-pipeline pass,
+//     4 costs registers for nothing on queues that rarely hold 256 tuples, 1 loses 10 % on table-sized sources.
 //   * fan-out without per-stage pending areas.  A step looks its candidates up, prefix-sums the run lengths and
 //     consumes the longest PREFIX of candidates whose outputs fit the next queue -- the rest stay where they are (in
 //     the queue, or in the source) and are looked up again later; a single candidate whose run alone exceeds the room
@@ -49,7 +51,7 @@
 #define POLR_CONST __attribute__((address_space(4)))
 
 #ifndef GEN_F
-#define GEN_F 4                 // candidates per lane and step
+#define GEN_F 2                 // candidates per lane and step
 #endif
 #define GEN_STEP (64 * GEN_F)   // candidates per step
 #define GEN_SCRATCH_DWORDS (2 * GEN_STEP) // run starts, inclusive prefix of run lengths
@@ -779,8 +781,11 @@ __device__ __forceinline__ void gen_step(GenCtx<W> &c, const uint32_t pos) {
 
 // ---- scheduler: one unit [in_pos, in_end), until nothing is left anywhere (a unit leaves nothing behind: its counters
 // are final when it arrives) -------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void gen_run_unit(GenCtx<W> &c) {
+// share(): called after every `share_after` steps spent on this unit (work sharing: polr_poolg.hip) -- it may take work
+// out of c (the back of the source range, part of a pending run, the bottom entries of a queue) between two steps
+template <int W, class ShareFn>
+__device__ __forceinline__ void gen_run_unit(GenCtx<W> &c, uint32_t share_after, ShareFn &&share) {
+	uint32_t steps = 0;
 	while (true) {
 		// deepest stage (>= 1) that has a pending run or a full step waiting
 		const bool stage_lane = c.lane >= 1u && c.lane < c.k;
@@ -799,5 +804,9 @@ __device__ __forceinline__ void gen_run_unit(GenCtx<W> &c) {
 			pick = (uint32_t)__builtin_ctzll(waiting);
 		}
 		gen_step<W>(c, gen_uni(pick));
+		if (++steps >= share_after) {
+			steps = 0;
+			share();
+		}
 	}
 }

@@ -166,10 +166,10 @@ hipError_t polr_launch_pool_kernel(uint32_t W, uint32_t k, uint32_t n_blocks, hi
                                    const ResidentExec *execs, PoolRun *run, DevOut out, bool ext);
 size_t polr_pool_flat_lds_bytes(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
 size_t polr_pool_flat_wave_bytes(uint32_t k);
-int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords);
+int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords, bool emit);
 hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords,
                                         hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                        PoolRun *run, DevOut out);
+                                        PoolRun *run, DevOut out, bool emit);
 void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,

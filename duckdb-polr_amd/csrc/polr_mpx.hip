@@ -59,6 +59,8 @@ struct polr_mpx {
 	uint32_t execs_cap = 0;
 	std::vector<char> execs_host;      // what execs_dev holds (a pass that repeats the last one re-sends nothing)
 	PoolSync *pool_dev = nullptr;      // unit rings of the runs this multiplexer leads
+	uint32_t *share_dev = nullptr;     // work sharing of the generic pipeline: one record per probe wave + its flag
+	size_t share_bytes = 0;
 	uint32_t pool_lo_cap = 0, pool_hi_cap = 0;
 	bool pool_dirty = false;           // a run was given up: rings and tickets are re-initialised before the next one
 	polr_mpx *leader = nullptr;        // the first multiplexer of the last pool run this one took part in (owns the rings)
@@ -297,7 +299,7 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
 	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, wq);
 	memset(info, 0, sizeof(*info));
 	info->waves_per_workgroup = wpb;
-	const int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
+	const int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords, mat) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
 	if (occ < 1) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "per-wave LDS queues exceed 160 KB (too many joins x carried ids)");
 	}
@@ -575,7 +577,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	const DevPipeline &dp = (materialize && !flat) ? p->host_mat : p->host_count;
 	const uint32_t wq = dp.W + (dp.mult ? 1u : 0u); // slots per queued tuple: ids (+ multiplicity)
 	const uint32_t wpb = flat ? p->flat_wpb : polr_pool_waves_per_block(dp.k, wq);
-	int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
+	int occ = wpb == 0 ? 0 : (flat ? polr_pool_flat_occupancy(dp.k, wpb, dp.lds_table_dwords, materialize) : polr_pool_occupancy(dp.k, wq, dp.ext != 0));
 	if (occ < 1) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "pool kernel does not fit on a CU (per-wave LDS queues: too many joins x carried ids)");
 	}
@@ -628,14 +630,38 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	const uint32_t lo_cap = next_pow2_u32(2ull * ((4ull * POLR_SLOTS * pool_waves + 17ull * POLR_SLOTS * n +
 	                                               (uint64_t)POLR_SLOTS * (p->n_tuples >> 16)) / R +
 	                                              (uint64_t)POLR_SLOTS * n + pool_waves / R + 16) + 64);
-	const uint32_t hi_cap =
-	    next_pow2_u32(2ull * ((uint64_t)POLR_SLOTS * n * (POLR_POOL_HI_TUPLES / POLR_POOL_HI_UNIT / R + 1)) + 64);
+	// (+ work sharing: a probe wave has at most one shared piece outstanding, published on the ring after its own)
+	const uint32_t hi_cap = next_pow2_u32(
+	    2ull * ((uint64_t)POLR_SLOTS * n * (POLR_POOL_HI_TUPLES / POLR_POOL_HI_UNIT / R + 1) + pool_waves / R + 1) + 64);
 	if (((volatile uint32_t *)m0->done_host)[2]) {
 		// an earlier run on these rings was given up (whoever finished it): probe waves left holding tickets
 		m0->pool_dirty = true;
 		if (!m0->pending_sync) {
 			((volatile uint32_t *)m0->done_host)[2] = 0; // (nothing in flight that could still report it)
 		}
+	}
+	// work sharing (generic pipeline only): records of 8 + 64 x (words per queued tuple) dwords, one per probe wave, and
+	// their flags -- all flags are 0 between runs (a record is released by the wave that took it) unless a run was given up
+	const uint32_t share_after = flat ? 0xFFFFFFFFu : (ctx->tuning.share_after ? ctx->tuning.share_after : 64u);
+	const uint32_t share_stride = 8u + 64u * wq;
+	uint32_t *share_recs = nullptr, *share_flags = nullptr;
+	if (share_after != 0xFFFFFFFFu) {
+		const size_t need = ((size_t)pool_waves * share_stride + pool_waves) * sizeof(uint32_t);
+		if (m0->share_bytes < need) {
+			if (m0->share_dev) {
+				HIPCHK(ctx, hipStreamSynchronize(st));
+				hipFree(m0->share_dev);
+				m0->share_dev = nullptr;
+				m0->share_bytes = 0;
+			}
+			HIPCHK(ctx, hipMalloc((void **)&m0->share_dev, need));
+			m0->share_bytes = need;
+			HIPCHK(ctx, hipMemsetAsync(m0->share_dev, 0, need, st));
+		} else if (m0->pool_dirty) {
+			HIPCHK(ctx, hipMemsetAsync(m0->share_dev, 0, m0->share_bytes, st));
+		}
+		share_recs = m0->share_dev;
+		share_flags = m0->share_dev + (size_t)pool_waves * share_stride;
 	}
 	if (!m0->pool_dev || m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap || m0->pool_dirty) {
 		if (m0->pool_dev && (m0->pool_lo_cap < lo_cap || m0->pool_hi_cap < hi_cap)) {
@@ -694,6 +720,10 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	hr->idle_sleep = ctx->tuning.idle_sleep == 16 ? 16u : 64u; // (an idle probe wave's longest back-off)
 	// watchdog: ticks of the 100 MHz wall clock (default 4 s: a wait this long is a lost run)
 	hr->timeout_ticks = ctx->tuning.watchdog_us ? (unsigned long long)ctx->tuning.watchdog_us * 100ull : POLR_RES_TIMEOUT_TICKS;
+	hr->share_recs = share_recs;
+	hr->share_flags = share_flags;
+	hr->share_stride = share_stride;
+	hr->share_after = share_after;
 	hr->routers_done = 0;
 	hr->abort = 0;
 	// the rings belong to the multiplexer that leads the run: a run that is given up says so in ITS host words too,
@@ -761,7 +791,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	const ResidentExec *execs_dev = (const ResidentExec *)(m0->execs_dev + POOL_HEADER_BYTES);
 	hipError_t e =
 	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
-	                                        (PoolRun *)m0->execs_dev, dout)
+	                                        (PoolRun *)m0->execs_dev, dout, materialize)
 	         : polr_launch_pool_kernel(wq, dp.k, n_blocks, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
 	                                   (PoolRun *)m0->execs_dev, dout, dp.ext != 0);
 	if (e != hipSuccess) {
@@ -1051,6 +1081,9 @@ void polr_mpx_destroy(polr_mpx *m) {
 	}
 	if (m->execs_dev) {
 		hipFree(m->execs_dev);
+	}
+	if (m->share_dev) {
+		hipFree(m->share_dev);
 	}
 	if (m->pool_dev) {
 		hipFree(m->pool_dev);

@@ -19,14 +19,21 @@
 #error "compile with -DPOLR_K=<compiled stage count>"
 #endif
 
+#ifndef POLR_FLAT_EMIT
+#define POLR_FLAT_EMIT 0 // two builds per K: counting runs (0) and runs whose last join writes row ids (1)
+#endif
+
 #include "polr_pool_common.h"
 #include "polr_flat_device.h"
 
 #define PASTE_TL2(a, b) a##b
 #define PASTE_TL(a, b) PASTE_TL2(a, b)
+#if !POLR_FLAT_EMIT
 POOL_DIAG_ENTRY(PASTE_TL(polr_diag_router_k, POLR_K), PASTE_TL(polr_diag_timeline_set_k, POLR_K))
+#endif
 
-template <int K>
+// (EMIT only tells the two builds' kernels apart by name: what differs is compiled in or out by POLR_FLAT_EMIT)
+template <int K, int EMIT>
 __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline *__restrict__ pipe,
                                                               const ResidentExec *__restrict__ execs, PoolRun *run,
                                                               DevOut out, uint32_t lds_per_wave, uint32_t table_dwords,
@@ -101,7 +108,9 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 			}
 			cur_path = u.path;
 		}
+#if POLR_FLAT_EMIT
 		c.emit = u.emit != 0 && out.ids != nullptr && !c.overflow;
+#endif
 		c.unit_begin = u.begin;
 		c.in_pos = u.begin;
 		c.in_end = (uint64_t)u.begin + u.count;
@@ -127,9 +136,11 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		}
 		u = nxt;
 	}
+#if POLR_FLAT_EMIT
 	if (c.cur_chunk != FLAT_NO_CHUNK && c.lane == 0) {
 		out.chunk_count[c.cur_chunk] = c.fill;
 	}
+#endif
 }
 
 // ---- launch ------------------------------------------------------------------------------------
@@ -151,7 +162,7 @@ static size_t pool_flat_lds_dwords(uint32_t waves_per_block, uint32_t table_dwor
 static hipError_t pool_flat_prepare(size_t lds) {
 	static size_t lds_set = 0;
 	if (lds > lds_set) {
-		hipError_t e = hipFuncSetAttribute((const void *)polr_pool_flat_kernel<POLR_K>,
+		hipError_t e = hipFuncSetAttribute((const void *)polr_pool_flat_kernel<POLR_K, POLR_FLAT_EMIT>,
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) {
 			return e;
@@ -161,6 +172,14 @@ static hipError_t pool_flat_prepare(size_t lds) {
 	return hipSuccess;
 }
 
+#if POLR_FLAT_EMIT
+#define FLAT_EXPORT(name) PASTE(PASTE(name, e_k), POLR_K)
+#else
+#define FLAT_EXPORT(name) PASTE(PASTE(name, k), POLR_K)
+#endif
+
+#if !POLR_FLAT_EMIT
+// (LDS layout and waves per workgroup are the same in both builds; both keep 128 VGPRs)
 extern "C++" size_t PASTE(polr_pool_flat_lds_bytes_k, POLR_K)(uint32_t waves_per_block, uint32_t table_dwords) {
 	return pool_flat_lds_dwords(waves_per_block, table_dwords) * sizeof(uint32_t);
 }
@@ -168,19 +187,20 @@ extern "C++" size_t PASTE(polr_pool_flat_lds_bytes_k, POLR_K)(uint32_t waves_per
 extern "C++" size_t PASTE(polr_pool_flat_wave_bytes_k, POLR_K)() {
 	return pool_flat_wave_dwords() * sizeof(uint32_t);
 }
+#endif
 
-extern "C++" int PASTE(polr_pool_flat_occupancy_k, POLR_K)(uint32_t waves_per_block, uint32_t table_dwords) {
+extern "C++" int FLAT_EXPORT(polr_pool_flat_occupancy_)(uint32_t waves_per_block, uint32_t table_dwords) {
 	const size_t lds = pool_flat_lds_dwords(waves_per_block, table_dwords) * sizeof(uint32_t);
 	int blocks = 0;
 	if (pool_flat_prepare(lds) != hipSuccess ||
-	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_pool_flat_kernel<POLR_K>,
+	    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *)polr_pool_flat_kernel<POLR_K, POLR_FLAT_EMIT>,
 	                                                 (int)(64 * waves_per_block), lds) != hipSuccess) {
 		return 0;
 	}
 	return blocks;
 }
 
-extern "C++" hipError_t PASTE(polr_launch_pool_flat_kernel_k, POLR_K)(uint32_t n_blocks, uint32_t waves_per_block,
+extern "C++" hipError_t FLAT_EXPORT(polr_launch_pool_flat_kernel_)(uint32_t n_blocks, uint32_t waves_per_block,
                                                                       uint32_t table_dwords, hipStream_t stream,
                                                                       const DevPipeline *pipe, const ResidentExec *execs,
                                                                       PoolRun *run, DevOut out) {
@@ -195,5 +215,5 @@ extern "C++" hipError_t PASTE(polr_launch_pool_flat_kernel_k, POLR_K)(uint32_t n
 	dim3 grid(n_blocks), block(64 * waves_per_block);
 	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&out, (void *)&per_wave, (void *)&table_dwords,
 	                (void *)&router_dwords};
-	return hipLaunchKernel((const void *)polr_pool_flat_kernel<POLR_K>, grid, block, args, lds, stream);
+	return hipLaunchKernel((const void *)polr_pool_flat_kernel<POLR_K, POLR_FLAT_EMIT>, grid, block, args, lds, stream);
 }

@@ -44,6 +44,10 @@ __device__ __forceinline__ void pool_load_run(const PoolRun *run, PoolRun &rh) {
 	rh.abort = 0;
 	rh.host_words = (volatile uint32_t *)uni64((uint64_t)run->host_words);
 	rh.timeout_ticks = uni64(run->timeout_ticks);
+	rh.share_recs = (uint32_t *)uni64((uint64_t)run->share_recs);
+	rh.share_flags = (uint32_t *)uni64((uint64_t)run->share_flags);
+	rh.share_stride = uni(run->share_stride);
+	rh.share_after = uni(run->share_after);
 }
 
 __device__ __forceinline__ void pool_load_exec(const ResidentExec *xp, ResidentExec &x) {
@@ -156,7 +160,7 @@ __device__ __forceinline__ void pool_arrive(const ResidentExec *execs, const Poo
 				seen |= __hip_atomic_fetch_add(&bank[p], (unsigned long long)cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
-		__hip_atomic_fetch_add(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, 1ull + (seen >> 63), __ATOMIC_RELAXED,
+		__hip_atomic_fetch_add(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, POLR_POOL_TOKENS + (seen >> 63), __ATOMIC_RELAXED,
 		                       __HIP_MEMORY_SCOPE_AGENT);
 	}
 #pragma unroll

@@ -19,7 +19,7 @@
 //             (PoolRoundOut).
 //   entry     two 8-byte granules, each carrying the lap tag of its ticket, written and read with relaxed
 //             agent-scope 8-byte atomics (self-validating, no fences):
-//               g0 = tag:16 | kind:2 | slot:2 | emit:1 | path:5 | 0:6 | begin:32
+//               g0 = tag:16 | kind:2 | slot:2 | emit:1 | path:5 | 0:1 | level:5 | begin:32
 //               g1 = tag:16 | exec:16 | count:32
 //   tickets   mid, lo: a wave takes the next ticket with one returning atomic add on the queue's head and looks for the
 //             entry of that ticket (tickets past the tail are simply not written yet; it keeps the ticket while it
@@ -30,8 +30,8 @@
 //             ahead on a shadow of the state while their decisions cannot depend on intermediates still outstanding
 //             (polr_can_speculate); each slot has its own counter bank and arrival counters.
 //   arrival   a wave adds its k stage counters to the executor's bank [slot][ring & 7][k] with returning atomics, then
-//             1 to arrived[slot][ring & 7]; the router waits for the sum of the 8 shards to reach the units it has
-//             published in that slot, exchanges the counters with 0 and routes.
+//             the unit's tokens (POLR_POOL_TOKENS) to arrived[slot][ring & 7]; the router waits for the sum of the 8 shards
+//             to reach the tokens of the units it has published in that slot, exchanges the counters with 0 and routes.
 //   exit      the router that finishes last publishes one EXIT entry per worker wave of every ring (lo).
 //   watchdog  every wait is bounded (POLR_RES_TIMEOUT_TICKS); a timeout raises `abort` in the run header, which every
 //             waiter polls: a lost wave is an error (POLR_E_HIP from polr_mpx_finish), never a hang.
@@ -68,6 +68,13 @@
 #define POLR_POOL_HI_UNIT 64u // smallest unit of a small round (ring capacities are sized for it)
 #define POLR_POOL_KIND_WORK 1u
 #define POLR_POOL_KIND_EXIT 2u
+#define POLR_POOL_KIND_CONT 3u // shared work of the generic pipeline: tuples that wait in front of a stage (polr_poolg.hip)
+// Arrivals are counted in TOKENS: a unit published by a router is worth POLR_POOL_TOKENS; a probe wave that gives part
+// of its unit to the pool (work sharing, polr_poolg.hip) halves what its own arrival is worth and hands the other half
+// on with the piece, `level` halvings deep (entry bits 32..36) -- the router waits for the tokens of the units it
+// published, however they were cut up on the way.
+#define POLR_POOL_TOKENS 65536ull
+#define POLR_POOL_MAX_LEVEL 16u
 
 struct PoolRingCtl { // one 128-byte line each
 	unsigned long long lo_head, pad0[15];
@@ -119,6 +126,9 @@ struct PoolRun {
 	volatile uint32_t *host_words;          // pinned words of the run's FIRST multiplexer (it owns the rings): [2] = 1 when
 	                                        // the run was given up, whichever router saw it
 	unsigned long long timeout_ticks;       // watchdog: longest wait, ticks of the 100 MHz wall clock
+	uint32_t *share_recs;                   // work sharing (generic pipeline): one record of share_stride dwords per probe wave,
+	uint32_t *share_flags;                  // and its "full" flag; nullptr: off
+	uint32_t share_stride, share_after;     // a wave shares after share_after steps on one unit, and again after as many
 	uint32_t worker_waves[POLR_POOL_RINGS]; // probe waves that poll ring r (EXIT entries to publish); read in place
 };
 
@@ -127,14 +137,19 @@ __device__ __forceinline__ uint32_t polr_pool_tag(unsigned long long ticket, uin
 }
 
 __device__ __forceinline__ unsigned long long polr_pool_g0(uint32_t tag, uint32_t kind, uint32_t slot, uint32_t emit,
-                                                           uint32_t path, uint32_t begin) {
+                                                           uint32_t path, uint32_t begin, uint32_t level = 0) {
 	return ((unsigned long long)tag << 48) | ((unsigned long long)(kind & 3u) << 46) |
 	       ((unsigned long long)(slot & 3u) << 44) | ((unsigned long long)(emit & 1u) << 43) |
-	       ((unsigned long long)(path & 31u) << 38) | begin;
+	       ((unsigned long long)(path & 31u) << 38) | ((unsigned long long)(level & 31u) << 32) | begin;
 }
 __device__ __forceinline__ unsigned long long polr_pool_g1(uint32_t tag, uint32_t exec, uint32_t count) {
 	return ((unsigned long long)tag << 48) | ((unsigned long long)(exec & 0xFFFFu) << 32) | count;
 }
+
+// a unit as a probe wave sees it
+struct PoolUnit {
+	uint32_t kind, slot, emit, path, exec, begin, count, level;
+};
 
 // what a router has decided for one round, as the publisher needs it
 // cls: which queue a round goes to.  0 = hi: a small round (an exploration slice) -- latency-critical, taken first;
@@ -247,6 +262,19 @@ __device__ __forceinline__ void polr_pool_publish(const PoolRun &run, PoolSync *
 	}
 }
 
+// one entry on ring `ring`'s hi queue, by one lane of a PROBE wave that shares its work (the hi queues are the ones idle
+// waves look at first, and nobody blocks on them): the wave's own slot, path and executor, `level` halvings deep
+__device__ __forceinline__ void polr_pool_publish_shared(PoolSync *sync, uint32_t ring, uint32_t lo_cap, uint32_t hi_cap,
+                                                         uint32_t kind, const PoolUnit &of, uint32_t begin, uint32_t count,
+                                                         uint32_t level) {
+	const unsigned long long ticket = atomicAdd(&sync->ctl[ring].hi_tail, 1ull);
+	PoolEntry *e = polr_pool_hi(sync, ring, lo_cap, hi_cap) + (ticket & (hi_cap - 1u));
+	const uint32_t tag = polr_pool_tag(ticket, hi_cap);
+	__hip_atomic_store(&e->g1, polr_pool_g1(tag, of.exec, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&e->g0, polr_pool_g0(tag, kind, of.slot, of.emit, of.path, begin, level), __ATOMIC_RELAXED,
+	                   __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one EXIT entry per probe wave of every ring (the router that finishes last); run: the header in global memory
 __device__ __forceinline__ void polr_pool_publish_exit(const PoolRun *run, const PoolRun &rh, PoolSync *sync, uint32_t lane) {
 	const uint32_t lo_cap = rh.lo_cap;
@@ -272,10 +300,6 @@ __device__ __forceinline__ void polr_pool_publish_exit(const PoolRun *run, const
 }
 
 // ---- worker side ---------------------------------------------------------------------------------
-struct PoolUnit {
-	uint32_t kind, slot, emit, path, exec, begin, count;
-};
-
 __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned long long g1, uint32_t tag, PoolUnit &u) {
 	if ((uint32_t)(g0 >> 48) != tag || (uint32_t)(g1 >> 48) != tag) {
 		return false;
@@ -284,6 +308,7 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 	u.slot = (uint32_t)(g0 >> 44) & 3u;
 	u.emit = (uint32_t)(g0 >> 43) & 1u;
 	u.path = (uint32_t)(g0 >> 38) & 31u;
+	u.level = (uint32_t)(g0 >> 32) & 31u;
 	u.begin = (uint32_t)g0;
 	u.exec = (uint32_t)(g1 >> 32) & 0xFFFFu;
 	u.count = (uint32_t)g1;
@@ -407,7 +432,7 @@ __device__ __forceinline__ uint32_t polr_pool_poll(PoolPoller &pp, PoolUnit &u, 
 	if (!polr_pool_decode(g0, g1, tag, u)) {
 		return POLR_POLL_LEAVE; // (a hi entry that never arrived: watchdog)
 	}
-	return u.kind == POLR_POOL_KIND_WORK ? POLR_POLL_WORK : POLR_POLL_LEAVE;
+	return u.kind == POLR_POOL_KIND_EXIT ? POLR_POLL_LEAVE : POLR_POLL_WORK;
 }
 
 // Take the next unit for this wave, waiting for one.  Returns false when the wave has to leave (EXIT entry, abort or
@@ -598,7 +623,7 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 #pragma unroll
 		for (uint32_t s = 0; s < POLR_SLOTS; s++) {
 			if (s == slot) {
-				target[s] += r.n_units;
+				target[s] += (unsigned long long)r.n_units * POLR_POOL_TOKENS;
 			}
 		}
 		n_pub++;

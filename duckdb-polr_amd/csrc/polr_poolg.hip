@@ -31,7 +31,7 @@ POOL_DIAG_ENTRY(polr_diag_router_g, polr_diag_timeline_set_g)
 
 // a probe wave reports a finished unit: its stage counters (returning atomics), then the arrival
 __device__ __forceinline__ void poolg_arrive(const ResidentExec *execs, const PoolUnit &u, uint32_t ring, uint32_t k, uint32_t &v_cnt_lo,
-                                             uint32_t &v_cnt_hi, uint32_t lane) {
+                                             uint32_t &v_cnt_hi, uint32_t lane, unsigned long long tokens) {
 	const POLR_GLOBAL ResidentExec *xp = as_global(execs) + u.exec;
 	POLR_GLOBAL unsigned long long *bank = as_global((unsigned long long *)uni64((uint64_t)xp->counts)) +
 	                                       (size_t)u.slot * POLR_NSHARD * POLR_KMAX +
@@ -49,7 +49,7 @@ __device__ __forceinline__ void poolg_arrive(const ResidentExec *execs, const Po
 		seen |= __shfl_xor(seen, d, 64);
 	}
 	if (lane == 0) {
-		__hip_atomic_fetch_add(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, 1ull + seen, __ATOMIC_RELAXED,
+		__hip_atomic_fetch_add(&sync->arrived[u.slot][ring & (POLR_POOL_SHARDS - 1u)].v, tokens + seen, __ATOMIC_RELAXED,
 		                       __HIP_MEMORY_SCOPE_AGENT);
 	}
 	v_cnt_lo = v_cnt_hi = 0;
@@ -95,16 +95,169 @@ __global__ __launch_bounds__(64 * POOLG_WAVES, 4) void polr_pool_gen_kernel(cons
 	PoolPoller pp;
 	polr_pool_poller_init(pp, run, rh.sync, ring, rh.lo_cap, rh.hi_cap, pool_wave / rh.n_rings, rh.hi_lottery, rh.idle_sleep,
 	                      rh.timeout_ticks);
+	// ---- work sharing ---------------------------------------------------------------------------------------------
+	// A unit is a few hundred source tuples, but with repeated build keys on several joins its work is their PRODUCT: on
+	// the JOB 25c shape one cast_info row meets 114 x 23 x 134 build rows, and the wave that drew it was still expanding
+	// when the rest of the pass had long finished (104 ms of a 375 ms pass, one wave).  A wave that has spent
+	// `share_after` steps on one unit therefore gives HALF of what it still has to do to the pool -- shallowest first:
+	// the back half of its source range (an ordinary unit), else half of a pending run of build rows or the bottom half
+	// of the tuples waiting in front of a stage (a CONT entry: the tuples travel through this wave's record in global
+	// memory) -- and again after as many steps; whoever takes the piece does the same.  The arrival tokens are halved
+	// with the work (polr_pool_device.h), the counters of every piece are added where the unit's would have been.
+	const uint32_t share_stride = rh.share_stride;
+	POLR_GLOBAL uint32_t *my_rec = as_global(rh.share_recs) + (size_t)pool_wave * share_stride;
+	POLR_GLOBAL uint32_t *share_flags = as_global(rh.share_flags);
+	const uint32_t to_ring = (ring + 1u) & (rh.n_rings - 1u);
+	const uint32_t share_budget = rh.pool_waves / rh.n_rings > 0u ? rh.pool_waves / rh.n_rings : 1u;
+	auto share = [&]() {
+		if (u.level >= POLR_POOL_MAX_LEVEL) {
+			return;
+		}
+		// only while the queue the piece goes to is short: pieces nobody has taken yet mean nobody is idle (and the ring
+		// capacities leave room for one piece per probe wave of a ring on top of what the routers can have in flight)
+		uint32_t backlog = 0;
+		if (c.lane == 0) {
+			const unsigned long long hh = __hip_atomic_load(&rh.sync->ctl[to_ring].hi_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long ht = __hip_atomic_load(&rh.sync->ctl[to_ring].hi_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			backlog = ht > hh ? (uint32_t)(ht - hh) : 0u;
+		}
+		if (uni(backlog) >= share_budget) {
+			return;
+		}
+		// (a) the source: everything behind the tuple in progress
+		const uint64_t from = c.in_pos + (gen_lane_get(c.v_grem, 0) ? 1u : 0u);
+		if (c.in_end > from + 1u) {
+			const uint32_t give = (uint32_t)((c.in_end - from) >> 1);
+			c.in_end -= give;
+			u.level++;
+			if (c.lane == 0) {
+				polr_pool_publish_shared(rh.sync, to_ring, rh.lo_cap, rh.hi_cap, POLR_POOL_KIND_WORK, u, (uint32_t)c.in_end, give,
+				                         u.level);
+			}
+			return;
+		}
+		// (b, c) a stage: this wave's record must be free (the last piece it gave away has been taken)
+		uint32_t busy = 0;
+		if (c.lane == 0) {
+			busy = __hip_atomic_load(&share_flags[pool_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (uni(busy)) {
+			return;
+		}
+		const bool stage_lane = c.lane < c.k;
+		const uint64_t run_m = __ballot(stage_lane && c.v_grem >= 256u);
+		const uint64_t q_m = __ballot(stage_lane && c.lane >= 1u && c.v_qsize >= 2u);
+		if ((run_m | q_m) == 0ull) {
+			return;
+		}
+		const uint32_t p = (uint32_t)__builtin_ctzll(run_m | q_m);
+		uint32_t n = 0, gstart = 0, grem = 0, position = 0;
+		if ((run_m >> p) & 1ull) {
+			// (b) the second half of stage p's pending run, with the tuple it belongs to (the source front / the queue top)
+			const uint32_t all = gen_lane_get(c.v_grem, p);
+			grem = all >> 1;
+			gstart = gen_lane_get(c.v_gstart, p) + (all - grem);
+			gen_lane_set(c.v_grem, p, all - grem);
+			n = 1;
+			if (p == 0) {
+				position = (uint32_t)c.in_pos;
+			} else {
+				const POLR_LDS uint32_t *qq = c.q + (size_t)(p - 1u) * W * c.qcap;
+				const uint32_t top = gen_lane_get(c.v_qsize, p) - 1u;
+				if (c.lane < (uint32_t)W) {
+					__hip_atomic_store(&my_rec[8u + c.lane * 64u], qq[c.lane * c.qcap + top], __ATOMIC_RELAXED,
+					                   __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+		} else {
+			// (c) the bottom half of the tuples waiting in front of stage p (consumed last); the others move down
+			POLR_LDS uint32_t *qq = c.q + (size_t)(p - 1u) * W * c.qcap;
+			const uint32_t qs = gen_lane_get(c.v_qsize, p);
+			n = qs >> 1;
+			n = n > 64u ? 64u : n;
+			if (c.lane < n) {
+#pragma unroll
+				for (int i = 0; i < W; i++) {
+					__hip_atomic_store(&my_rec[8u + (uint32_t)i * 64u + c.lane], qq[i * c.qcap + c.lane], __ATOMIC_RELAXED,
+					                   __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			const uint32_t left = qs - n;
+			for (uint32_t b0 = 0; b0 < left; b0 += 64u) {
+				const uint32_t idx = b0 + c.lane;
+				uint32_t w[W];
+#pragma unroll
+				for (int i = 0; i < W; i++) {
+					w[i] = idx < left ? qq[i * c.qcap + idx + n] : 0u;
+				}
+#pragma unroll
+				for (int i = 0; i < W; i++) {
+					if (idx < left) {
+						qq[i * c.qcap + idx] = w[i];
+					}
+				}
+			}
+			gen_lane_set(c.v_qsize, p, left);
+		}
+		if (c.lane < 5u) {
+			const uint32_t h = c.lane == 0 ? p : (c.lane == 1 ? n : (c.lane == 2 ? gstart : (c.lane == 3 ? grem : position)));
+			__hip_atomic_store(&my_rec[c.lane], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		// the record is in memory before the entry that names it can be seen
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		u.level++;
+		if (c.lane == 0) {
+			__hip_atomic_store(&share_flags[pool_wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			polr_pool_publish_shared(rh.sync, to_ring, rh.lo_cap, rh.hi_cap, POLR_POOL_KIND_CONT, u, pool_wave, n, u.level);
+		}
+	};
+	const uint32_t share_after = rh.share_recs ? rh.share_after : 0xFFFFFFFFu;
 	TL_BEGIN(rh.n_router_blocks)
 	while (polr_pool_next_unit(pp, u, c.lane)) {
 		TL_GOT
 		c.stages = stages + (size_t)u.path * POLR_KMAX;
 		c.emit = u.emit != 0 && !c.overflow;
-		c.in_pos = u.begin;
-		c.in_end = (uint64_t)u.begin + u.count;
-		gen_run_unit<W>(c);
+		if (u.kind == POLR_POOL_KIND_CONT) {
+			// a piece of somebody's unit: u.begin names the record it waits in
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			const POLR_GLOBAL uint32_t *rec = as_global(rh.share_recs) + (size_t)u.begin * share_stride;
+			uint32_t h = 0;
+			if (c.lane < 5u) {
+				h = __hip_atomic_load(&rec[c.lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			const uint32_t p = gen_lane_get(h, 0), n = gen_lane_get(h, 1), gstart = gen_lane_get(h, 2), grem = gen_lane_get(h, 3),
+			               position = gen_lane_get(h, 4);
+			c.in_pos = c.in_end = 0;
+			if (grem != 0u && p == 0u) {
+				c.in_pos = position;
+				c.in_end = (uint64_t)position + 1u;
+			} else {
+				POLR_LDS uint32_t *qq = c.q + (size_t)(p - 1u) * W * c.qcap;
+				if (c.lane < n) {
+#pragma unroll
+					for (int i = 0; i < W; i++) {
+						qq[i * c.qcap + c.lane] =
+						    __hip_atomic_load(&rec[8u + (uint32_t)i * 64u + c.lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+				gen_lane_set(c.v_qsize, p, n);
+			}
+			if (grem != 0u) {
+				gen_lane_set(c.v_gstart, p, gstart);
+				gen_lane_set(c.v_grem, p, grem);
+			}
+			// (the tuples are in LDS: the record may be written again)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			if (c.lane == 0) {
+				__hip_atomic_store(&share_flags[u.begin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		} else {
+			c.in_pos = u.begin;
+			c.in_end = (uint64_t)u.begin + u.count;
+		}
+		gen_run_unit<W>(c, share_after, share);
 		TL_RUN
-		poolg_arrive(execs, u, ring, k, c.v_cnt_lo, c.v_cnt_hi, c.lane);
+		poolg_arrive(execs, u, ring, k, c.v_cnt_lo, c.v_cnt_hi, c.lane, POLR_POOL_TOKENS >> u.level);
 		TL_DONE(u)
 	}
 	if (c.cur_chunk != GEN_NO_CHUNK && c.lane == 0) {

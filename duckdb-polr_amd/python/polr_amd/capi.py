@@ -53,7 +53,7 @@ class PoolTuning(C.Structure):
     """polr_pool_tuning: 0 = the library's default"""
     _fields_ = [("device_share", C.c_uint32), ("units_x", C.c_uint32), ("hi_unit", C.c_uint32),
                 ("hi_lottery", C.c_uint32), ("hi_tuples_p1", C.c_uint32), ("idle_sleep", C.c_uint32),
-                ("watchdog_us", C.c_uint32), ("reserved", C.c_uint32)]
+                ("watchdog_us", C.c_uint32), ("share_after", C.c_uint32)]
 
 
 class JoinDesc(C.Structure):

@@ -99,7 +99,10 @@ typedef struct polr_pool_tuning {
 	uint32_t hi_tuples_p1; /* 1 + the size up to which a round counts as small (default 4096); 0: default */
 	uint32_t idle_sleep;   /* 16: an idle probe wave's back-off stays at s_sleep 16 (default 64) */
 	uint32_t watchdog_us;  /* microseconds; default 4 000 000 */
-	uint32_t reserved;     /* 0 */
+	uint32_t share_after;  /* work sharing (pipelines with repeated build keys): a probe wave that has spent this many
+	                          steps on ONE unit gives half of what it still has to do -- the rest of its source range,
+	                          of a run of build rows, or of the tuples waiting between two joins -- to the pool, and
+	                          again after as many steps (16..65535; default 64); 0xFFFFFFFF: never */
 } polr_pool_tuning;
 int polr_ctx_set_pool_tuning(polr_ctx *ctx, const polr_pool_tuning *tuning);
 

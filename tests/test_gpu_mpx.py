@@ -306,3 +306,81 @@ def test_a_given_up_run_leaves_the_rings_usable(gpu_ctx):
     for m in ms:
         m.close()
     pipe.close()
+
+
+def _product_fanout(n_fact=30_000, n_hot=4, reps=48, seed=11):
+    """three joins with repeated build keys on the same probe column -- a hot key meets reps^3 build-row triples -- each
+    feeding a small dimension keyed by ITS payload, so that every build id is needed downstream (nothing folds into a
+    multiplicity): the JOB 25c situation, where one source tuple is hundreds of thousands of pairs"""
+    rng = np.random.default_rng(seed)
+    n_m = 4_000
+    m_keys = (np.arange(n_m, dtype=np.int64) * 7 + 3).astype(np.int32)
+    hot = m_keys[rng.choice(n_m, n_hot, replace=False)]
+    fact_keys = m_keys[rng.integers(0, n_m, n_fact)]
+    fact_keys[rng.choice(n_fact, 20, replace=False)] = hot[rng.integers(0, n_hot, 20)]
+    fact = {"id": np.arange(n_fact, dtype=np.int32), "mk": fact_keys.astype(np.int32)}
+    joins = []
+    for x, name in enumerate(("mi", "mi_idx", "mk")):
+        r = rng.integers(0, 3, size=n_m)
+        r[np.isin(m_keys, hot)] = reps - 8 * x
+        b = np.repeat(m_keys, r)
+        b = b[rng.permutation(len(b))]
+        joins.append({"name": name, "keys": [b.astype(np.int32)], "key_names": ["movie_id"],
+                      "payload": {"t": (rng.integers(0, 5, len(b)) + 10 * x).astype(np.int32)}, "key_src": [(-1, 1)],
+                      "perfect": None})
+    for x, name in enumerate(("it1", "it2", "k")):
+        keys = (np.arange(4, dtype=np.int32) + 10 * x).astype(np.int32)  # 4 of the 5 payload values survive
+        joins.append({"name": name, "keys": [keys], "key_names": ["id"], "payload": {"v": keys * 3},
+                      "key_src": [(x, 0)], "perfect": (int(keys.min()), int(keys.max()))})
+    return {"name": "product_fanout", "probe": {"name": "fact", "cols": fact}, "joins": joins}
+
+
+@pytest.mark.parametrize("share_after", [16, 0xFFFFFFFF])
+def test_work_sharing_keeps_every_count(gpu_ctx, share_after):
+    """work sharing (polr_pool_tuning.share_after): a probe wave that is long on one unit hands parts of it to the pool --
+    the back of its source range, half of a run of build rows, half of the tuples waiting in front of a stage.  Whatever is
+    cut where, the routing trace (intermediates per round), every per-position counter, COUNT(*) and the materialised row
+    set are those of the oracle -- with sharing after 16 steps (it happens hundreds of times here) and with sharing off"""
+    from polr_amd import host
+    wl = _product_fanout()
+    k = len(wl["joins"])
+    # (BoundReference index of every join's probe-side key: 2 probe columns, then one payload column per join)
+    gen = host.generate_join_orders("each_last_once", len(wl["probe"]["cols"]), [len(j["payload"]) for j in wl["joins"]],
+                                    [[1], [1], [1], [2], [3], [4]], [len(j["keys"][0]) for j in wl["joins"]],
+                                    max_join_orders=4)
+    paths = gen[0]
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    n = len(pcols[0])
+    ref = orc.run_pipeline(pcols, ojoins, paths, routing="adaptive_reinit", caching=False, collect_output=True)
+    assert ref["num_intermediates"] > 2_000_000
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    pipe = capi.Pipeline(gpu_ctx, pcols, n, joins, paths)
+    n_chunks = (n + 1023) // 1024
+    try:
+        gpu_ctx.set_pool_tuning(share_after=share_after)
+        # counting run
+        mpx = capi.DeviceMultiplexer(pipe, "adaptive_reinit")
+        capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+        st = mpx.finish()
+        _, _, inter = mpx.fetch_log()
+        assert list(inter) == list(ref["intermediates_per_round"])
+        assert st["num_intermediates"] == ref["num_intermediates"]
+        assert st["input_tuple_count_per_path"] == ref["input_tuple_count_per_path"][:len(paths)]
+        assert sum(st["stage_out"][p][k - 1] for p in range(len(paths))) == ref["num_output_rows"]
+        mpx.close()
+        # emitting run: the row set
+        mpx = capi.DeviceMultiplexer(pipe, "adaptive_reinit")
+        out = capi.Output(pipe, 1024, ref["num_output_rows"] // 1024 + 4096)
+        mpx.run_resident(0, n_chunks, out=out)
+        st = mpx.finish()
+        assert st["num_intermediates"] == ref["num_intermediates"]
+        cols = []
+        for src_join, arr, valid in common.output_columns(wl):
+            src = wl["probe"]["cols"] if src_join < 0 else wl["joins"][src_join]["payload"]
+            col_idx = [i for i, a in enumerate(src.values()) if a is arr][0]
+            cols.append(out.materialize(src_join, col_idx, arr.dtype))
+        assert common.rows_digest_from_columns(cols) == common.oracle_output_digest(wl, ref["out_rows"])
+        mpx.close()
+    finally:
+        gpu_ctx.set_pool_tuning()
+    pipe.close()
