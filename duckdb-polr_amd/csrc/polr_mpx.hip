@@ -642,7 +642,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	}
 	// work sharing (generic pipeline only): records of 8 + 64 x (words per queued tuple) dwords, one per probe wave, and
 	// their flags -- all flags are 0 between runs (a record is released by the wave that took it) unless a run was given up
-	const uint32_t share_after = flat ? 0xFFFFFFFFu : (ctx->tuning.share_after ? ctx->tuning.share_after : 64u);
+	const uint32_t share_after = flat ? 0xFFFFFFFFu : (ctx->tuning.share_after ? ctx->tuning.share_after : 32u);
 	const uint32_t share_stride = 8u + 64u * wq;
 	uint32_t *share_recs = nullptr, *share_flags = nullptr;
 	if (share_after != 0xFFFFFFFFu) {
