@@ -54,6 +54,10 @@ __device__ __forceinline__ bool build_key(const DevCol *keys, uint32_t n_keys, u
 	for (uint32_t c = 0; c < n_keys; c++) {
 		const DevCol col = keys[c];
 		if (col.valid && !col.valid[r]) {
+			if (pack.packed && ((pack.null_eq >> c) & 1u)) {
+				key |= (pack.range[c] + 1u) << pack.shift[c]; // IS NOT DISTINCT FROM: the row stays, NULL is a key value
+				continue;
+			}
 			valid = false;
 		}
 		if (pack.packed) {
@@ -66,20 +70,21 @@ __device__ __forceinline__ bool build_key(const DevCol *keys, uint32_t n_keys, u
 	return valid;
 }
 
-// per key column: min and max of the (sign- or zero-extended) values of the rows whose keys are all valid, compared
+// per key column: min and max of the (sign- or zero-extended) values of the rows that enter the table -- a NULL key
+// drops the row unless its column is in null_eq (IS NOT DISTINCT FROM), where the cell itself is skipped -- compared
 // as int64; out[2c] = min, out[2c+1] = max (initialised to INT64_MAX / INT64_MIN by the launcher)
-__global__ void polr_key_minmax_kernel(const DevCol *__restrict__ keys, uint32_t n_keys, uint64_t n_rows,
+__global__ void polr_key_minmax_kernel(const DevCol *__restrict__ keys, uint32_t n_keys, uint64_t n_rows, uint32_t null_eq,
                                        long long *out) {
 	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	bool valid = r < n_rows;
 	for (uint32_t c = 0; c < n_keys && valid; c++) {
-		if (keys[c].valid && !keys[c].valid[r]) {
+		if (keys[c].valid && !keys[c].valid[r] && !((null_eq >> c) & 1u)) {
 			valid = false;
 		}
 	}
 	for (uint32_t c = 0; c < n_keys; c++) {
 		long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
-		if (valid) {
+		if (valid && !(keys[c].valid && !keys[c].valid[r])) {
 			lo = hi = (long long)build_cell(keys[c], r, (keys[c].flags & 1u) != 0);
 		}
 		for (int d = 32; d > 0; d >>= 1) {
@@ -433,9 +438,10 @@ extern "C++" void polr_launch_deserialize_col(hipStream_t st, const uint8_t *row
 }
 
 extern "C++" void polr_launch_key_minmax(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows,
-                                         long long *out /* [2 * n_keys], initialised by the caller */) {
+                                         uint32_t null_eq, long long *out /* [2 * n_keys], initialised by the caller */) {
 	if (n_rows) {
-		hipLaunchKernelGGL(polr_key_minmax_kernel, grid1d(n_rows, 256), dim3(256), 0, st, keys_dev, n_keys, n_rows, out);
+		hipLaunchKernelGGL(polr_key_minmax_kernel, grid1d(n_rows, 256), dim3(256), 0, st, keys_dev, n_keys, n_rows, null_eq,
+		                   out);
 	}
 }
 

@@ -250,6 +250,11 @@ static bool needs_key_pack(const polr_ht *ht) {
 	if (ht->n_keys >= 3) {
 		return true;
 	}
+	for (uint32_t c = 0; c < ht->n_keys; c++) {
+		if (ht->key_flags[c]) {
+			return true; // compared by value (a CAST on one side) or NULL = NULL: the packed form does both exactly
+		}
+	}
 	return ht->n_keys == 2 && (ht->keys[0].width > 4 || ht->keys[1].width > 4);
 }
 
@@ -377,6 +382,22 @@ int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32
 	return POLR_OK;
 }
 
+int polr_ht_set_key_flags(polr_ht *ht, uint32_t key_col, uint32_t flags) {
+	POLR_ENTRY();
+	if (!ht) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = ht->ctx;
+	if (ht->kind != KIND_NONE) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "key flags are set before the table is finalized");
+	}
+	if (key_col >= ht->n_keys || (flags & ~(POLR_KEY_BY_VALUE | POLR_KEY_NULL_EQUAL))) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "key column %u of %u, flags 0x%x", key_col, ht->n_keys, flags);
+	}
+	ht->key_flags[key_col] = flags;
+	return POLR_OK;
+}
+
 int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
 	POLR_ENTRY();
 	if (!ht) {
@@ -404,7 +425,12 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
 		}
 		hipError_t e = hipMemcpyAsync(mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, st);
 		if (e == hipSuccess) {
-			polr_launch_key_minmax(st, ht->keys_dev, ht->n_keys, n, mm);
+			uint32_t null_eq = 0;
+			for (uint32_t c = 0; c < ht->n_keys; c++) {
+				null_eq |= (ht->key_flags[c] & POLR_KEY_NULL_EQUAL) ? (1u << c) : 0u;
+			}
+			ht->pack.null_eq = null_eq;
+			polr_launch_key_minmax(st, ht->keys_dev, ht->n_keys, n, null_eq, mm);
 			e = hipMemcpyAsync(h_mm, mm, sizeof(h_mm), hipMemcpyDeviceToHost, st);
 		}
 		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
@@ -413,16 +439,20 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
 			POLR_FAIL(ctx, POLR_E_HIP, "key range scan failed: %s", hipGetErrorString(e));
 		}
 		uint32_t shift = 0;
+		const uint32_t null_eq_mask = ht->pack.null_eq;
 		ht->pack.packed = 1;
 		for (uint32_t c = 0; c < ht->n_keys; c++) {
 			const bool empty = h_mm[2 * c] > h_mm[2 * c + 1]; // no row with valid keys at all
 			const int64_t lo = empty ? 0 : h_mm[2 * c], hi = empty ? 0 : h_mm[2 * c + 1];
 			const uint64_t range = (uint64_t)hi - (uint64_t)lo;
+			// (a NULL = NULL column has one more code, range + 1: NULL)
+			const bool null_eq_col = ((null_eq_mask >> c) & 1u) != 0;
+			const uint64_t top = range + (null_eq_col ? 1u : 0u);
 			uint32_t bits = 0;
-			while (bits < 64 && (range >> bits) != 0) {
+			while (bits < 64 && (top >> bits) != 0) {
 				bits++;
 			}
-			if (shift + bits > 64) {
+			if (shift + bits > 64 || (null_eq_col && top == 0)) {
 				ht->pack = KeyPack();
 				POLR_FAIL(ctx, POLR_E_UNSUPPORTED,
 				          "composite key of %u columns needs more than 64 bits (column %u: range %llu after %u bits)",
@@ -501,7 +531,7 @@ int polr_ht_finalize_hash(polr_ht *ht, void *stream) {
 		}
 	}
 	if (!rc) {
-		const bool unique32 = ht->max_run <= 1 && ht->n_keys == 1 && ht->keys[0].width == 4;
+		const bool unique32 = ht->max_run <= 1 && ht->n_keys == 1 && ht->keys[0].width == 4 && !ht->pack.packed;
 		if (unique32) {
 			uint2 *s8 = nullptr;
 			rc = dev_alloc(ctx, (void **)&s8, capacity * sizeof(uint2), &ht->device_bytes);
@@ -577,6 +607,10 @@ int polr_ht_finalize_perfect(polr_ht *ht, int64_t min_value, int64_t max_value, 
 	}
 	if (ht->n_keys != 1) {
 		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "perfect hash join needs exactly one key (plan_comparison_join.cpp:63-133)");
+	}
+	if (ht->key_flags[0]) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "a key compared by value (CAST) or with NULL = NULL takes a hash table "
+		                                   "(the reference plans perfect hash joins for plain equalities only)");
 	}
 	const bool is_signed = ht->key_signed != 0;
 	const uint64_t range = is_signed ? (uint64_t)(max_value - min_value) : (uint64_t)max_value - (uint64_t)min_value;
@@ -680,7 +714,7 @@ int polr_ht_finalize_auto(polr_ht *ht, int64_t min_value, int64_t max_value, voi
 	int rc = POLR_E_DUPLICATE;
 	const bool is_signed = ht->key_signed != 0;
 	const bool ordered = is_signed ? max_value >= min_value : (uint64_t)max_value >= (uint64_t)min_value;
-	if (ht->kind == KIND_NONE && ht->n_keys == 1 && ordered && ht->n_rows_in > 0) {
+	if (ht->kind == KIND_NONE && ht->n_keys == 1 && ordered && ht->n_rows_in > 0 && !ht->key_flags[0]) {
 		const uint64_t range = is_signed ? (uint64_t)(max_value - min_value) : (uint64_t)max_value - (uint64_t)min_value;
 		// dense keys of any range, and -- like the reference's planner, plan_comparison_join.cpp:118,125 -- any key
 		// whose range is at most 1 M values (a 125 KB bit table, however few of its bits are set: a filtered dimension)
@@ -841,6 +875,7 @@ struct HtMeta {
 	int64_t min_value, max_value;
 	uint32_t key_width[POLR_MAX_KEYS];
 	uint32_t key_flags[POLR_MAX_KEYS];
+	uint32_t key_sem[POLR_MAX_KEYS]; // POLR_KEY_* (polr_ht_set_key_flags)
 	KeyPack pack;
 	uint32_t payload_width[62];
 	uint32_t payload_flags[62];
@@ -919,6 +954,7 @@ int polr_ht_export(const polr_ht *ht, void *meta, uint64_t *meta_bytes, void **d
 	for (uint32_t i = 0; i < ht->n_keys; i++) {
 		m.key_width[i] = ht->keys[i].width;
 		m.key_flags[i] = ht->keys[i].flags;
+		m.key_sem[i] = ht->key_flags[i];
 	}
 	m.pack = ht->pack;
 	const std::vector<OwnedCol> &cols = ht->kind == KIND_PERFECT ? ht->pcols : ht->payload;
@@ -969,6 +1005,7 @@ int polr_ht_alloc_like(polr_ctx *ctx, const void *meta, uint64_t meta_bytes, pol
 		ht->keys[i].width = m.key_width[i];
 		ht->keys[i].flags = m.n_keys == 1 ? m.key_signed : m.key_flags[i];
 		ht->keys[i].owned = false;
+		ht->key_flags[i] = m.key_sem[i];
 	}
 	ht->pack = m.pack;
 	int rc = POLR_OK;
@@ -1066,6 +1103,13 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 			valid = col.valid;
 		}
 	};
+	// width and signedness of the column a key is READ from (a key compared by value may differ from the build column)
+	auto source_type = [&](int32_t sj, int32_t sc, uint32_t &width, uint32_t &sx) {
+		const OwnedCol &col = sj < 0 ? p->probe_cols[sc]
+		                             : (p->hts[sj]->kind == KIND_PERFECT ? p->hts[sj]->pcols[sc] : p->hts[sj]->payload[sc]);
+		width = col.width;
+		sx = (col.flags & 1u) ? 1u : 0u;
+	};
 	for (uint32_t q = 0; q < dp.n_paths; q++) {
 		for (uint32_t pos = 0; pos < dp.k; pos++) {
 			const uint32_t j = dp.paths[q].order[pos];
@@ -1087,7 +1131,7 @@ static void build_stage_descs(const polr_pipeline *p, const DevPipeline &dp, std
 				StageExt x;
 				memset(&x, 0, sizeof(x));
 				for (uint32_t c = 0; c < dj.n_keys; c++) {
-					x.key_width[c] = dj.key_width[c];
+					source_type(dj.key_src_join[c], dj.key_src_col[c], x.key_width[c], x.key_sx[c]);
 					source(dj.key_src_join[c], dj.key_src_col[c], x.key_slot[c], x.key_data[c], x.key_valid[c]);
 				}
 				x.pack = ht->pack;
@@ -1303,11 +1347,17 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 				}
 				width = joins[sj].ht->payload[sc].width;
 			}
-			// JoinHashTable asserts left/right key types equal (join_hashtable.cpp:24); a CAST'ed probe
-			// key must be materialised by the caller first
-			if (width != ht->keys[c].width) {
-				POLR_FAIL(ctx, POLR_E_INVALID, "join %u key %u: probe key is %u bytes, build key %u bytes", j, c, width,
-				          ht->keys[c].width);
+			// JoinHashTable asserts left/right key types equal (join_hashtable.cpp:24): the reference's left side is then
+			// CAST(column) (polar_config.cpp:75-82).  An integer cast is a comparison by VALUE, which a table whose key
+			// column carries POLR_KEY_BY_VALUE does on the device -- no materialised copy of the probe column
+			if (width != ht->keys[c].width && !(ht->key_flags[c] & POLR_KEY_BY_VALUE)) {
+				POLR_FAIL(ctx, POLR_E_INVALID,
+				          "join %u key %u: probe key is %u bytes, build key %u bytes (a CAST'ed key: polr_ht_set_key_flags(..., "
+				          "POLR_KEY_BY_VALUE) before the table is finalized)",
+				          j, c, width, ht->keys[c].width);
+			}
+			if (width != 1 && width != 2 && width != 4 && width != 8) {
+				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u key %u: probe key of %u bytes", j, c, width);
 			}
 		}
 		if (joins[j].n_preds > POLR_MAX_PREDS) {

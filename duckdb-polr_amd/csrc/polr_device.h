@@ -60,8 +60,9 @@ enum { KIND_NONE = 0, KIND_PERFECT = 1, KIND_S8 = 2, KIND_S16 = 3 };
 struct KeyPack {
 	uint32_t packed; // 0: plain form
 	uint32_t shift[POLR_NKEYS];
-	uint32_t sx[POLR_NKEYS]; // sign-extend column c
-	uint32_t pad[3];
+	uint32_t sx[POLR_NKEYS]; // sign-extend column c (the BUILD column; the probe side's: StageExt::key_sx)
+	uint32_t null_eq;        // bit c: IS NOT DISTINCT FROM on column c -- NULL is the code range[c] + 1, on both sides
+	uint32_t pad[2];
 	int64_t min[POLR_NKEYS];
 	uint64_t range[POLR_NKEYS];
 };
@@ -109,7 +110,8 @@ struct DevPath {
 // unit differs from the last one's).
 struct StageExt {
 	// every key column of the join, in packed form (KeyPack)
-	uint32_t key_width[POLR_NKEYS];
+	uint32_t key_width[POLR_NKEYS]; // of the column the PROBE side reads (a CAST'ed key: not the build column's)
+	uint32_t key_sx[POLR_NKEYS];    // ... and whether it is sign-extended
 	int32_t key_slot[POLR_NKEYS];
 	const uint8_t *key_data[POLR_NKEYS];
 	const uint8_t *key_valid[POLR_NKEYS];

@@ -189,13 +189,18 @@ __device__ __attribute__((noinline)) bool gen_fetch_key_packed(const POLR_GLOBAL
 	for (uint32_t c = 0; c < n_keys; c++) {
 		const uint32_t row = gen_slot<W>(t, d->key_slot[c]);
 		const POLR_GLOBAL uint8_t *kv = (const POLR_GLOBAL uint8_t *)d->key_valid[c];
-		if (kv && !kv[row]) {
-			valid = false;
-		}
 		const uint32_t w = d->key_width[c];
-		const uint64_t v = gen_load_cell((const POLR_GLOBAL uint8_t *)d->key_data[c] + (uint64_t)row * w, w, d->pack.sx[c] != 0);
-		const uint64_t off = v - (uint64_t)d->pack.min[c];
-		if (off > d->pack.range[c]) {
+		// (by VALUE: the probe column's own width and signedness -- a CAST'ed key; a value outside the build side's range
+		// cannot match, whichever type could or could not hold it)
+		const uint64_t v = gen_load_cell((const POLR_GLOBAL uint8_t *)d->key_data[c] + (uint64_t)row * w, w, d->key_sx[c] != 0);
+		uint64_t off = v - (uint64_t)d->pack.min[c];
+		if (kv && !kv[row]) {
+			if ((d->pack.null_eq >> c) & 1u) {
+				off = d->pack.range[c] + 1u; // IS NOT DISTINCT FROM: NULL is a key value of its own
+			} else {
+				valid = false;
+			}
+		} else if (off > d->pack.range[c]) {
 			valid = false;
 		}
 		key |= off << d->pack.shift[c];

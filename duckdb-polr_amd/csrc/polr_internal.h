@@ -49,6 +49,7 @@ struct polr_ht {
 	polr_ctx *ctx = nullptr;
 	uint32_t n_keys = 0, n_payload = 0;
 	KeyPack pack = {}; // composite keys in packed form (finalize_hash decides)
+	uint32_t key_flags[POLR_MAX_KEYS] = {}; // POLR_KEY_* per key column (polr_ht_set_key_flags, before finalize)
 	uint64_t n_rows_in = 0; // rows as uploaded (build row ids index these)
 	uint64_t n_rows = 0;    // rows kept (NULL keys dropped)
 	std::vector<OwnedCol> keys, payload;
@@ -178,7 +179,8 @@ void polr_launch_reduce_counts(hipStream_t stream, const unsigned long long *src
                                unsigned long long *dst);
 void polr_launch_deserialize_col(hipStream_t st, const uint8_t *rows, uint64_t n_rows, uint32_t row_width, uint32_t col,
                                  uint32_t offset, uint32_t width, uint8_t *dst, uint8_t *dst_valid);
-void polr_launch_key_minmax(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows, long long *out);
+void polr_launch_key_minmax(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, uint64_t n_rows, uint32_t null_eq,
+                            long long *out);
 void polr_launch_s16_build(hipStream_t st, const DevCol *keys_dev, uint32_t n_keys, const KeyPack &pack, uint64_t n_rows,
                            uint4 *slots,
                            uint64_t capacity, uint32_t *slot_of_row, uint32_t *cursor, uint32_t *rowids,

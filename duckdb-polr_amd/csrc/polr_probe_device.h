@@ -166,13 +166,16 @@ __device__ __attribute__((noinline)) bool fetch_key_packed(const StageExt *d, ui
 	for (uint32_t c = 0; c < n_keys; c++) {
 		const uint32_t row = tuple_slot<W>(t, d->key_slot[c]);
 		const uint8_t *kv = d->key_valid[c];
-		if (kv && !kv[row]) {
-			valid = false;
-		}
 		const uint32_t w = d->key_width[c];
-		const uint64_t v = load_cell(d->key_data[c] + (uint64_t)row * w, w, d->pack.sx[c] != 0);
-		const uint64_t off = v - (uint64_t)d->pack.min[c];
-		if (off > d->pack.range[c]) {
+		const uint64_t v = load_cell(d->key_data[c] + (uint64_t)row * w, w, d->key_sx[c] != 0); // (the probe column's own type)
+		uint64_t off = v - (uint64_t)d->pack.min[c];
+		if (kv && !kv[row]) {
+			if ((d->pack.null_eq >> c) & 1u) {
+				off = d->pack.range[c] + 1u; // IS NOT DISTINCT FROM: NULL is a key value of its own
+			} else {
+				valid = false;
+			}
+		} else if (off > d->pack.range[c]) {
 			valid = false;
 		}
 		key |= off << d->pack.shift[c];

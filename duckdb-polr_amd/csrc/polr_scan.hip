@@ -421,6 +421,9 @@ int polr_pipeline_scan_filter_lip(polr_pipeline *p, void *stream, const polr_sca
 			if (dj.n_keys != 1 || dj.key_src_join[0] >= 0) {
 				POLR_FAIL(ctx, POLR_E_INVALID, "LIP: join %u is not keyed by one column of the source (physical_join.cpp:57-107)", j);
 			}
+			if (p->hts[j]->pack.packed) {
+				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "LIP: join %u compares its key by value / NULL = NULL (packed form)", j);
+			}
 			js.push_back(j);
 		}
 		if (lip_joins >> p->k) {

@@ -23,7 +23,9 @@ PhysicalHashJoin::PhysicalHashJoin(polr_ctx *ctx_p, vector<LogicalType> probe_ty
 		throw InternalException("hash join needs one type per condition");
 	}
 	for (idx_t c = 0; c < conditions.size(); c++) {
-		(conditions[c].comparison == ExpressionType::COMPARE_EQUAL ? equality_conditions : other_conditions).push_back(c);
+		const bool keyed = conditions[c].comparison == ExpressionType::COMPARE_EQUAL ||
+		                   conditions[c].comparison == ExpressionType::COMPARE_NOT_DISTINCT_FROM; // (join_hashtable.cpp:24-32)
+		(keyed ? equality_conditions : other_conditions).push_back(c);
 	}
 	if (equality_conditions.empty()) {
 		throw InternalException("a hash join needs at least one equality condition (plan_comparison_join.cpp)");
@@ -74,11 +76,22 @@ void PhysicalHashJoin::SinkBuildSide(const vector<Vector> &keys, const vector<Ve
 	Check(ctx, polr_ht_upload_columns(ctx, kc.data(), (uint32_t)kc.size(), pc.data(), (uint32_t)pc.size(), count,
 	                                  &hash_table),
 	      "polr_ht_upload_columns");
+	// key semantics: IS NOT DISTINCT FROM keeps NULL keys and lets them match; a CAST'ed probe key is compared by value
+	bool plain_keys = true;
+	for (idx_t i = 0; i < equality_conditions.size(); i++) {
+		const JoinCondition &cond = conditions[equality_conditions[i]];
+		const uint32_t flags = (cond.comparison == ExpressionType::COMPARE_NOT_DISTINCT_FROM ? POLR_KEY_NULL_EQUAL : 0u) |
+		                       (cond.left_is_cast ? POLR_KEY_BY_VALUE : 0u);
+		if (flags) {
+			Check(ctx, polr_ht_set_key_flags(hash_table, (uint32_t)i, flags), "polr_ht_set_key_flags");
+			plain_keys = false;
+		}
+	}
 	build_count = count;
 	uses_perfect_hash = false;
 	// physical_hash_join.cpp:463-473: try the perfect table when the planner marked the build small;
 	// a duplicate key falls back to the hash table (perfect_hash_join_executor.cpp:112-114)
-	if (perfect_join_statistics.is_build_small && conditions.size() == 1 && other_conditions.empty()) {
+	if (perfect_join_statistics.is_build_small && conditions.size() == 1 && other_conditions.empty() && plain_keys) {
 		int rc = polr_ht_finalize_perfect(hash_table, perfect_join_statistics.build_min,
 		                                  perfect_join_statistics.build_max, nullptr);
 		if (rc == POLR_OK) {
@@ -126,12 +139,14 @@ unique_ptr<OperatorState> PhysicalHashJoin::MakeState(const vector<idx_t> &key_c
 	vector<polr_col> cols;
 	vector<uint8_t> ones(STANDARD_VECTOR_SIZE, 1);
 	for (idx_t c = 0; c < conditions.size(); c++) {
-		zeros.emplace_back(STANDARD_VECTOR_SIZE * condition_types[c].width, 0);
+		// (a CAST'ed left side is staged in the probe column's OWN type: the device compares by value)
+		const LogicalType &t = conditions[c].left_is_cast ? probe_types[conditions[c].left_index] : condition_types[c];
+		zeros.emplace_back(STANDARD_VECTOR_SIZE * t.width, 0);
 		polr_col pc;
 		pc.data = zeros.back().data();
 		pc.valid = ones.data();
-		pc.width = condition_types[c].width;
-		pc.flags = condition_types[c].is_signed ? POLR_COL_SIGNED : 0;
+		pc.width = t.width;
+		pc.flags = t.is_signed ? POLR_COL_SIGNED : 0;
 		cols.push_back(pc);
 	}
 	polr_join_desc jd;
@@ -247,8 +262,8 @@ OperatorResultType PhysicalHashJoin::Execute(ExecutionContext &context, DataChun
 	// resolve the join keys for the left chunk (:669-670): flatten through the dictionary selection
 	for (idx_t c = 0; c < conditions.size(); c++) {
 		const Vector &kv = input.data[state.key_columns[c]];
-		if (!(kv.type == condition_types[c])) {
-			throw InternalException("probe key type differs from the build key type (CAST must be materialised)");
+		if (!(kv.type == (conditions[c].left_is_cast ? probe_types[conditions[c].left_index] : condition_types[c]))) {
+			throw InternalException("probe key type differs from the build key type and the condition carries no CAST");
 		}
 		const idx_t w = kv.type.width;
 		vector<uint8_t> cells(n * w + 1), valid(n + 1, 1);

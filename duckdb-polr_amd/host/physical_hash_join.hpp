@@ -12,8 +12,11 @@
 
 namespace duckdb_polr {
 
-// the probe side of a JoinCondition: a BoundReferenceExpression (or CAST of one, which the caller must
-// have materialised) on the probe chunk (joinside.hpp:17-36, polar_config.cpp:75-82)
+// the probe side of a JoinCondition: a BoundReferenceExpression on the probe chunk (joinside.hpp:17-36).  A CAST of one
+// (`left_is_cast`): POLARConfig::GenerateJoinOrders means to accept it (polar_config.cpp:75-82) but tests for
+// ExpressionType::CAST where a bound cast carries OPERATOR_CAST, so the reference never multiplexes a pipeline with a
+// CAST'ed key; the mirror does the same (MakePolarConfigForPipeline returns "do not multiplex").  The operator itself
+// takes such a key: integer casts are compared by value on the device (POLR_KEY_BY_VALUE), no cast copy is made
 // the comparison of a join condition (values of src/include/duckdb/common/enums/expression_type.hpp:34-46)
 enum class ExpressionType : uint8_t {
 	COMPARE_EQUAL = 25,
@@ -21,7 +24,8 @@ enum class ExpressionType : uint8_t {
 	COMPARE_LESSTHAN = 27,
 	COMPARE_GREATERTHAN = 28,
 	COMPARE_LESSTHANOREQUALTO = 29,
-	COMPARE_GREATERTHANOREQUALTO = 30
+	COMPARE_GREATERTHANOREQUALTO = 30,
+	COMPARE_NOT_DISTINCT_FROM = 40 // (a key condition: NULL = NULL, JoinHashTable::null_values_are_equal join_hashtable.cpp:35-36)
 };
 
 // JoinCondition (src/include/duckdb/planner/joinside.hpp:22-41): left = a column of the probe chunk, right = a column
@@ -30,6 +34,7 @@ enum class ExpressionType : uint8_t {
 struct JoinCondition {
 	idx_t left_index = 0;
 	bool left_is_bound_ref = true;
+	bool left_is_cast = false; // CAST(BoundReference): left_index names the column under the cast
 	ExpressionType comparison = ExpressionType::COMPARE_EQUAL;
 };
 

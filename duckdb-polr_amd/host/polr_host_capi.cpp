@@ -454,4 +454,68 @@ int64_t polr_host_hash_join_probe_cond(polr_ctx *ctx, const int32_t *build_keys,
 	}
 }
 
+// One join whose key is compared by VALUE across types and / or with NULL = NULL: probe column INTEGER; build key BIGINT
+// when cast != 0 (the condition's left side is then CAST(column), JoinCondition::left_is_cast) else INTEGER; comparison
+// IS NOT DISTINCT FROM when null_equal != 0 (COMPARE_NOT_DISTINCT_FROM).  (probe row, payload cell) pairs.
+int64_t polr_host_hash_join_probe_keysem(polr_ctx *ctx, const void *build_keys, const uint8_t *build_key_valid,
+                                         const int32_t *build_payload, uint64_t n_build, int cast, int null_equal,
+                                         const int32_t *probe_keys, const uint8_t *probe_valid, uint64_t n_probe,
+                                         uint32_t *out_probe_row, int32_t *out_payload, uint64_t out_cap) {
+	try {
+		ClientContext client;
+		ThreadContext thread;
+		ExecutionContext ec(client, thread);
+		JoinCondition cond;
+		cond.left_index = 0;
+		cond.left_is_cast = cast != 0;
+		cond.comparison = null_equal ? ExpressionType::COMPARE_NOT_DISTINCT_FROM : ExpressionType::COMPARE_EQUAL;
+		const LogicalType key_type = cast ? LogicalType::BIGINT() : LogicalType::INTEGER();
+		PhysicalHashJoin join(ctx, {LogicalType::INTEGER()}, {key_type}, {LogicalType::INTEGER()}, {cond}, JoinType::INNER,
+		                      n_build);
+		const idx_t nb = n_build ? n_build : 1;
+		Vector bk(key_type, nb), bp(LogicalType::INTEGER(), nb);
+		memcpy(bk.data, build_keys, n_build * key_type.width);
+		if (build_key_valid) {
+			bk.EnsureValidity(nb);
+			memcpy(bk.validity, build_key_valid, n_build);
+		}
+		memcpy(bp.data, build_payload, n_build * 4);
+		join.SinkBuildSide({bk}, {bp}, n_build);
+		auto state = join.GetOperatorState(ec);
+		uint64_t n_out = 0;
+		for (uint64_t base = 0; base < n_probe; base += STANDARD_VECTOR_SIZE) {
+			const idx_t n = std::min<idx_t>(STANDARD_VECTOR_SIZE, n_probe - base);
+			DataChunk input, chunk;
+			input.Initialize({LogicalType::INTEGER()});
+			memcpy(input.data[0].data, probe_keys + base, n * 4);
+			if (probe_valid) {
+				input.data[0].EnsureValidity(STANDARD_VECTOR_SIZE);
+				memcpy(input.data[0].validity, probe_valid + base, n);
+			}
+			input.SetCardinality(n);
+			for (;;) {
+				chunk.Initialize(join.types);
+				auto r = join.Execute(ec, input, chunk, *join.op_state, *state);
+				if (r == OperatorResultType::FINISHED) {
+					break;
+				}
+				for (idx_t i = 0; i < chunk.size(); i++) {
+					if (n_out < out_cap) {
+						out_probe_row[n_out] = (uint32_t)(base + chunk.data[0].sel.get_index(i));
+						memcpy(&out_payload[n_out], chunk.data[1].Cell(i), 4);
+					}
+					n_out++;
+				}
+				if (r == OperatorResultType::NEED_MORE_INPUT) {
+					break;
+				}
+			}
+		}
+		return (int64_t)n_out;
+	} catch (std::exception &e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+
 } // extern "C"

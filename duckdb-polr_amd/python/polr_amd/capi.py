@@ -35,7 +35,7 @@ EXPORTS = [
     "polr_ht_finalize_auto", "polr_pipeline_launch_info", "polr_pipeline_scan_filter", "polr_pipeline_fetch_scan", "polr_mpx_use_scan_chunks", "polr_out_aggregate", "polr_out_aggregate_grouped",
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
     "polr_ctx_set_pool_tuning", "polr_ctx_get_stream",
-    "polr_ht_set_payload_heap", "polr_pipeline_set_probe_heap", "polr_out_aggregate_string",
+    "polr_ht_set_payload_heap", "polr_pipeline_set_probe_heap", "polr_out_aggregate_string", "polr_ht_set_key_flags",
 ]
 
 
@@ -47,6 +47,9 @@ class PolrError(RuntimeError):
 
 class Col(C.Structure):
     _fields_ = [("data", C.c_void_p), ("valid", C.c_void_p), ("width", C.c_uint32), ("flags", C.c_uint32)]
+
+
+KEY_BY_VALUE, KEY_NULL_EQUAL = 1, 2  # polr_ht_set_key_flags
 
 
 class PoolTuning(C.Structure):
@@ -137,6 +140,7 @@ def load():
     L.polr_ctx_set_pool_tuning.argtypes = [vp, C.POINTER(PoolTuning)]
     L.polr_ctx_get_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.polr_ht_set_payload_heap.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    L.polr_ht_set_key_flags.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.polr_pipeline_set_probe_heap.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.polr_out_aggregate_string.argtypes = [vp, vp, C.c_uint32, C.c_int32, C.c_uint32, C.c_char_p, C.c_uint32,
                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -309,6 +313,11 @@ class HashTable:
         ctx.check(ctx.L.polr_ht_upload_columns(ctx.h, _col_array(key_cols), len(key_cols), _col_array(payload_cols),
                                                len(payload_cols), n_rows, C.byref(h)))
         return cls(ctx, h)
+
+    def set_key_flags(self, key_col, flags):
+        """polr_ht_set_key_flags (before finalize): KEY_BY_VALUE = the probe side may read another integer type (a CAST'ed
+        key), KEY_NULL_EQUAL = IS NOT DISTINCT FROM"""
+        self.ctx.check(self.ctx.L.polr_ht_set_key_flags(self.h, key_col, flags))
 
     def set_payload_heap(self, payload_col, heap):
         """polr_ht_set_payload_heap: the string heap the cells of payload column `payload_col` point into (before finalize)"""
@@ -812,8 +821,13 @@ def build_joins(ctx, wl, auto=False):
                                     key_valid=j.get("key_valid"), payload_valid=pv + [None] * len(strs))
         for i, (_c, heap) in enumerate(strs):
             ht.set_payload_heap(len(j["payload"]) + i, heap)
+        # j["key_flags"]: per key column KEY_BY_VALUE (the probe side reads another integer type: a CAST'ed key) and / or
+        # KEY_NULL_EQUAL (IS NOT DISTINCT FROM)
+        for c, f in enumerate(j.get("key_flags", [])):
+            if f:
+                ht.set_key_flags(c, f)
         done = False
-        if auto and len(j["keys"]) == 1 and j["keys"][0].dtype.kind in "iu" and len(j["keys"][0]):
+        if auto and not any(j.get("key_flags", [])) and len(j["keys"]) == 1 and j["keys"][0].dtype.kind in "iu" and len(j["keys"][0]):
             kv = j.get("key_valid")
             kk = j["keys"][0] if not kv or kv[0] is None else j["keys"][0][kv[0].astype(bool)]
             if len(kk):

@@ -225,6 +225,33 @@ def hash_join_probe(ctx, build_keys, build_payload, probe_keys, probe_valid=None
     return rows[:n].copy(), pay[:n].copy(), calls.value
 
 
+def hash_join_probe_keysem(ctx, build_keys, build_payload, probe_keys, build_key_valid=None, probe_valid=None, cast=False,
+                           null_equal=False):
+    """PhysicalHashJoin whose one condition is `CAST(probe AS BIGINT) = build` (cast: build_keys are int64) and / or
+    `probe IS NOT DISTINCT FROM build` (null_equal), chunk by chunk through Execute()"""
+    L = load()
+    bk = np.ascontiguousarray(build_keys, dtype=np.int64 if cast else np.int32)
+    bp = np.ascontiguousarray(build_payload, dtype=np.int32)
+    pk = np.ascontiguousarray(probe_keys, dtype=np.int32)
+    bv = None if build_key_valid is None else np.ascontiguousarray(build_key_valid, dtype=np.uint8)
+    pv = None if probe_valid is None else np.ascontiguousarray(probe_valid, dtype=np.uint8)
+    cap = max(1024, 64 * len(pk))
+    rows = np.zeros((cap,), dtype=np.uint32)
+    pay = np.zeros((cap,), dtype=np.int32)
+    L.polr_host_hash_join_probe_keysem.restype = C.c_int64
+    L.polr_host_hash_join_probe_keysem.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_int, C.c_int] + [C.c_void_p] * 2 + \
+        [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    n = L.polr_host_hash_join_probe_keysem(ctx.h, bk.ctypes.data, None if bv is None else bv.ctypes.data, bp.ctypes.data,
+                                           len(bk), int(cast), int(null_equal), pk.ctypes.data,
+                                           None if pv is None else pv.ctypes.data, len(pk), rows.ctypes.data,
+                                           pay.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError(L.polr_host_last_error().decode())
+    if n > cap:
+        raise RuntimeError("output larger than the test buffer")
+    return rows[:n].copy(), pay[:n].copy()
+
+
 COMPARISON = {"<>": 26, "<": 27, ">": 28, "<=": 29, ">=": 30}  # ExpressionType, expression_type.hpp:34-46
 
 

@@ -144,6 +144,70 @@ def chain_dep(n_fact=120_000, seed=SEED):
 
 
 # -------------------------------------------------------------------------------------------------
+# key semantics beyond "same type, NULL never matches": a CAST'ed key (INTEGER probe column against a BIGINT build key: the
+# binder wraps the left side in CAST, which POLARConfig accepts, polar_config.cpp:75-82) and IS NOT DISTINCT FROM
+# (JoinHashTable::null_values_are_equal, join_hashtable.cpp:35-36), next to a plain join
+# -------------------------------------------------------------------------------------------------
+KEY_BY_VALUE, KEY_NULL_EQUAL = 1, 2  # (polr_hip.h: POLR_KEY_*)
+
+
+def key_semantics(n_fact=24_000, seed=SEED, cast=True):
+    """cast=False: without dim_a -- the reference never multiplexes a pipeline one of whose keys is CAST'ed (it tests
+    ExpressionType::CAST where a bound cast is OPERATOR_CAST, polar_config.cpp:78), so only this form has a reference run
+    under the multiplexer"""
+    rng = _rng(seed, 7)
+    n_a, n_b, n_c, n_d = 3_000, 400, 900, 64
+    a_keys = (np.arange(n_a, dtype=np.int64) * 5 - 2_000)            # BIGINT, negative values included
+    a_keys[::97] += 1 << 33                                          # ... and some no INTEGER can hold
+    b_keys = (np.arange(n_b, dtype=np.int32) * 3 + 1).astype(np.int32)
+    b_keys = np.concatenate([b_keys, b_keys[:60]])                   # repeated keys
+    b_valid = np.ones(len(b_keys), dtype=np.uint8)
+    b_valid[rng.choice(len(b_keys), 25, replace=False)] = 0          # 25 build rows whose key is NULL
+    c_keys = (np.arange(n_c, dtype=np.int32) + 50).astype(np.int32)
+    d_keys = (np.arange(n_d, dtype=np.int32) * 2).astype(np.int32)
+    fa = (rng.integers(0, n_a + 400, n_fact) * 5 - 2_000).astype(np.int32)  # (the tail misses dimension a)
+    fa_valid = (rng.random(n_fact) < 0.97).astype(np.uint8)
+    fb = np.where(rng.random(n_fact) < 0.8, b_keys[rng.integers(0, n_b, n_fact)], 2).astype(np.int32)
+    fb_valid = (rng.random(n_fact) < 0.9).astype(np.uint8)           # 10 % NULL: they meet the 25 NULL build rows
+    fc = np.where(rng.random(n_fact) < 0.7, c_keys[rng.integers(0, n_c, n_fact)], 7).astype(np.int32)
+    phase = (np.arange(n_fact) * 4 // n_fact)                        # d is selective in the second half of the table
+    fd = np.where((phase < 2) | (rng.random(n_fact) < 0.2), d_keys[rng.integers(0, n_d, n_fact)], 1).astype(np.int32)
+    fact = {"id": np.arange(n_fact, dtype=np.int32), "a": fa, "b": fb, "c": fc, "d": fd}
+    perm_b = rng.permutation(len(b_keys))
+    ja = {"name": "dim_a", "keys": [a_keys[rng.permutation(n_a)]], "key_names": ["k"],
+          "payload": {"pa": None}, "key_src": [(-1, 1)], "perfect": None, "key_flags": [KEY_BY_VALUE]}
+    ja["payload"]["pa"] = (ja["keys"][0] % 1000).astype(np.int32)
+    jb = {"name": "dim_b", "keys": [b_keys[perm_b]], "key_names": ["k"], "key_valid": [b_valid[perm_b]],
+          "payload": {"pb": (np.arange(len(b_keys)) % 13).astype(np.int32)}, "key_src": [(-1, 2)], "perfect": None,
+          "key_flags": [KEY_NULL_EQUAL]}
+    jc = {"name": "dim_c", "keys": [c_keys[rng.permutation(n_c)]], "key_names": ["k"],
+          "payload": {"pc": None}, "key_src": [(-1, 3)], "perfect": (int(c_keys.min()), int(c_keys.max()))}
+    jc["payload"]["pc"] = (jc["keys"][0] * 7 % 101).astype(np.int32)
+    jd = {"name": "dim_d", "keys": [d_keys[rng.permutation(n_d)]], "key_names": ["k"],
+          "payload": {"pd": None}, "key_src": [(-1, 4)], "perfect": (int(d_keys.min()), int(d_keys.max()))}
+    jd["payload"]["pd"] = (jd["keys"][0] + 5).astype(np.int32)
+    joins = ([ja] if cast else []) + [jb, jc, jd]
+    wl = {"name": "key_semantics", "probe": {"name": "fact", "cols": fact, "valid": {"a": fa_valid, "b": fb_valid}},
+          "joins": joins, "cond_left_index": ([[1]] if cast else []) + [[2], [3], [4]]}
+    # the same for the reference: NULLs travel as a sentinel no key uses and are set by UPDATEs after the load
+    NULL_A, NULL_B = -2_000_000_000, -2_000_000_001
+    t_fact = {"id": fact["id"], "a": np.where(fa_valid != 0, fa, NULL_A).astype(np.int32),
+              "b": np.where(fb_valid != 0, fb, NULL_B).astype(np.int32), "c": fc, "d": fd}
+    t_b = {"k": np.where(jb["key_valid"][0] != 0, jb["keys"][0], NULL_B).astype(np.int32), "pb": jb["payload"]["pb"]}
+    wl["ref"] = {
+        "tables": {"fact": t_fact, "dim_a": {"k": ja["keys"][0], "pa": ja["payload"]["pa"]}, "dim_b": t_b,
+                   "dim_c": {"k": jc["keys"][0], "pc": jc["payload"]["pc"]},
+                   "dim_d": {"k": jd["keys"][0], "pd": jd["payload"]["pd"]}},
+        "pk": {},
+        "settings": ["UPDATE fact SET a = NULL WHERE a = %d" % NULL_A, "UPDATE fact SET b = NULL WHERE b = %d" % NULL_B,
+                     "UPDATE dim_b SET k = NULL WHERE k = %d" % NULL_B,
+                     "SET disabled_optimizers TO 'join_order,statistics_propagation'"],
+        "query": "SELECT COUNT(*) FROM fact " + ("JOIN dim_a ON fact.a = dim_a.k " if cast else "") +
+                 "JOIN dim_b ON fact.b IS NOT DISTINCT FROM dim_b.k JOIN dim_c ON fact.c = dim_c.k JOIN dim_d ON fact.d = dim_d.k"}
+    return wl
+
+
+# -------------------------------------------------------------------------------------------------
 # heavy fan-out (JOB's cast_info / movie_info style duplicates)
 # -------------------------------------------------------------------------------------------------
 def fanout(n_fact=40_000, seed=SEED):

@@ -127,10 +127,23 @@ int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32
                         const uint32_t *col_offset, const uint32_t *col_width, const uint32_t *col_flags,
                         uint32_t n_keys, uint32_t n_payload, polr_ht **out);
 /* Same from columnar build data (DataChunks as sunk by PhysicalHashJoin::Sink,
- * physical_hash_join.cpp:217-286).  Rows with a NULL key are dropped (join_hashtable.cpp:170-192),
- * row ids still refer to the rows as passed. */
+ * physical_hash_join.cpp:217-286).  Rows with a NULL key are dropped (join_hashtable.cpp:170-192) unless the
+ * column is POLR_KEY_NULL_EQUAL; row ids still refer to the rows as passed. */
 int polr_ht_upload_columns(polr_ctx *ctx, const polr_col *keys, uint32_t n_keys, const polr_col *payload,
                            uint32_t n_payload, uint64_t n_rows, polr_ht **out);
+/* Key semantics beyond "same type on both sides, NULL never matches": the reference multiplexes INNER hash joins whose
+ * left side is CAST(column) (src/parallel/polar_config.cpp:75-82) and whose comparison is IS NOT DISTINCT FROM
+ * (JoinHashTable::null_values_are_equal, src/execution/join_hashtable.cpp:35-36,170-192,642).  Per key column, BEFORE the
+ * table is finalized:
+ *   POLR_KEY_BY_VALUE    compare this column BY VALUE whatever integer type the probe side reads (an integer CAST on
+ *                        either side of the condition): widths and signedness of the two sides may differ, a probe
+ *                        value the build side does not hold never matches.  No cast copy of the probe column is made.
+ *   POLR_KEY_NULL_EQUAL  IS NOT DISTINCT FROM: NULL = NULL on this column; build rows whose key is NULL there are kept.
+ * A table with such a column is a hash table with its key in packed form (polr_ht_finalize_hash, _auto;
+ * polr_ht_finalize_perfect refuses: the reference plans perfect hash joins for plain equalities only). */
+#define POLR_KEY_BY_VALUE 1u
+#define POLR_KEY_NULL_EQUAL 2u
+int polr_ht_set_key_flags(polr_ht *ht, uint32_t key_col, uint32_t flags);
 /* Finalize as a hash table (JoinHashTable::Finalize / InsertHashes, join_hashtable.cpp:305-377). */
 int polr_ht_finalize_hash(polr_ht *ht, void *stream);
 /* Finalize as a perfect hash table (BuildPerfectHashTable, perfect_hash_join_executor.cpp:20-122):

@@ -114,6 +114,7 @@ struct orc_ht {
 	uint8_t **hash_map; /* capacity head pointers (NULL = empty) */
 	uint32_t *orig_row; /* HT row ordinal -> build table row */
 	int has_null;
+	int key_null_equal[ORC_MAX_KEYS]; /* JoinHashTable::null_values_are_equal (join_hashtable.cpp:35-36) */
 };
 
 static idx_t next_pow2(idx_t v) {
@@ -135,10 +136,23 @@ static idx_t next_pow2(idx_t v) {
  * bucket chain (InsertHashesLoop<false> :296-301), overwriting the stored hash with the previous
  * head ("next") pointer. capacity = PointerTableCapacity (join_hashtable.hpp:265-267). */
 orc_ht_t *orc_ht_build(const orc_col_t *keys, int n_keys, const orc_col_t *payload, int n_payload, idx_t n_rows) {
+	return orc_ht_build2(keys, n_keys, payload, n_payload, n_rows, NULL);
+}
+
+/* null_equal[c] != 0: key column c is compared with IS NOT DISTINCT FROM (COMPARE_NOT_DISTINCT_FROM,
+ * join_hashtable.cpp:35-36): PrepareKeys does not filter its NULLs (:182), on either side; a NULL hashes to
+ * HashOp::NULL_HASH (vector_hash.cpp:15-19) and is serialised as an invalid cell of the row; RowOperations::Match lets
+ * an invalid probe value match exactly the rows whose cell is invalid (row_match.cpp:73-83). */
+#define ORC_NULL_HASH 0xbf58476d1ce4e5b9ull
+orc_ht_t *orc_ht_build2(const orc_col_t *keys, int n_keys, const orc_col_t *payload, int n_payload, idx_t n_rows,
+                        const int *null_equal) {
 	if (n_keys < 1 || n_keys > ORC_MAX_KEYS || n_payload > 63) {
 		return NULL;
 	}
 	orc_ht_t *ht = (orc_ht_t *)calloc(1, sizeof(orc_ht_t));
+	for (int i = 0; i < n_keys; i++) {
+		ht->key_null_equal[i] = null_equal ? null_equal[i] : 0;
+	}
 	ht->n_keys = n_keys;
 	ht->n_payload = n_payload;
 	int ncols = n_keys + n_payload + 1;
@@ -166,7 +180,7 @@ orc_ht_t *orc_ht_build(const orc_col_t *keys, int n_keys, const orc_col_t *paylo
 	for (idx_t r = 0; r < n_rows; r++) {
 		int is_null = 0;
 		for (int i = 0; i < n_keys; i++) {
-			if (keys[i].valid && !keys[i].valid[r]) {
+			if (keys[i].valid && !keys[i].valid[r] && !ht->key_null_equal[i]) {
 				is_null = 1;
 			}
 		}
@@ -179,8 +193,15 @@ orc_ht_t *orc_ht_build(const orc_col_t *keys, int n_keys, const orc_col_t *paylo
 		uint64_t h = 0;
 		for (int i = 0; i < n_keys; i++) {
 			const uint8_t *src = (const uint8_t *)keys[i].data + r * (idx_t)keys[i].width;
-			memcpy(row + ht->offsets[i], src, (size_t)keys[i].width);
-			uint64_t hv = orc_hash_value(src, keys[i].width, keys[i].is_signed);
+			uint64_t hv;
+			if (keys[i].valid && !keys[i].valid[r]) { /* (a null-equal column: the row stays, its cell is invalid) */
+				row[i / 8] &= (uint8_t) ~(1u << (i % 8));
+				memset(row + ht->offsets[i], 0, (size_t)keys[i].width);
+				hv = ORC_NULL_HASH;
+			} else {
+				memcpy(row + ht->offsets[i], src, (size_t)keys[i].width);
+				hv = orc_hash_value(src, keys[i].width, keys[i].is_signed);
+			}
 			h = i == 0 ? hv : orc_combine_hash(h, hv); /* JoinHashTable::Hash :141-155 */
 		}
 		for (int i = 0; i < n_payload; i++) {
@@ -1051,9 +1072,14 @@ static void next_inner_join(exec_t *e, const int32_t *path, int pos, join_state_
 			for (int c = 0; c < j->n_keys && match; c++) {
 				int valid;
 				const uint8_t *cell = key_cell(e, path, left, idx, join_idx, c, &valid);
-				/* TemplatedMatchType<T, Equals, NO_MATCH_SEL=false>: row validity bit && equal */
-				if (!valid || !row_col_valid(ht, row, c) ||
-				    memcmp(cell, row + ht->offsets[c], (size_t)ht->key_width[c]) != 0) {
+				/* TemplatedMatchType<T, Equals, NO_MATCH_SEL=false>: row validity bit && equal; an invalid probe value (only
+				 * a null-equal column lets one get this far) matches exactly the invalid cells (row_match.cpp:73-83) */
+				if (!valid) {
+					if (row_col_valid(ht, row, c)) {
+						match = 0;
+					}
+				} else if (!row_col_valid(ht, row, c) ||
+				           memcmp(cell, row + ht->offsets[c], (size_t)ht->key_width[c]) != 0) {
 					match = 0;
 				}
 			}
@@ -1162,11 +1188,11 @@ static int hash_join_execute(exec_t *e, const int32_t *path, int pos, join_state
 		for (int c = 0; c < j->n_keys; c++) {
 			int valid;
 			const uint8_t *cell = key_cell(e, path, input, i, join_idx, c, &valid);
-			if (!valid) {
+			if (!valid && !ht->key_null_equal[c]) {
 				all_valid = 0;
 				break;
 			}
-			uint64_t hv = orc_hash_value(cell, ht->key_width[c], ht->key_signed[c]);
+			uint64_t hv = valid ? orc_hash_value(cell, ht->key_width[c], ht->key_signed[c]) : ORC_NULL_HASH;
 			h = c == 0 ? hv : orc_combine_hash(h, hv);
 		}
 		if (!all_valid) {

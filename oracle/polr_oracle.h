@@ -72,6 +72,9 @@ uint64_t orc_combine_hash(uint64_t a, uint64_t b);
  *      :284-377 (InsertHashes/Finalize), src/common/types/row_layout.cpp:19-80 ---- */
 typedef struct orc_ht orc_ht_t;
 orc_ht_t *orc_ht_build(const orc_col_t *keys, int n_keys, const orc_col_t *payload, int n_payload, idx_t n_rows);
+/* null_equal[c] != 0: IS NOT DISTINCT FROM on key column c (NULL = NULL; such rows stay in the table) */
+orc_ht_t *orc_ht_build2(const orc_col_t *keys, int n_keys, const orc_col_t *payload, int n_payload, idx_t n_rows,
+                        const int *null_equal);
 void orc_ht_free(orc_ht_t *ht);
 idx_t orc_ht_count(const orc_ht_t *ht);
 idx_t orc_ht_capacity(const orc_ht_t *ht);

@@ -86,6 +86,8 @@ def lib():
         L.orc_combine_hash.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_ht_build.restype = C.c_void_p
         L.orc_ht_build.argtypes = [C.POINTER(_Col), C.c_int, C.POINTER(_Col), C.c_int, C.c_uint64]
+        L.orc_ht_build2.restype = C.c_void_p
+        L.orc_ht_build2.argtypes = [C.POINTER(_Col), C.c_int, C.POINTER(_Col), C.c_int, C.c_uint64, C.POINTER(C.c_int)]
         L.orc_ht_free.argtypes = [C.c_void_p]
         for f in ("orc_ht_count", "orc_ht_capacity", "orc_ht_row_width", "orc_ht_pointer_offset"):
             getattr(L, f).restype = C.c_uint64
@@ -166,7 +168,8 @@ def _cols(pairs):
 class HashTable:
     """Reference-layout chained hash table (JoinHashTable) built on the CPU."""
 
-    def __init__(self, keys, payload=(), key_valid=None, payload_valid=None):
+    def __init__(self, keys, payload=(), key_valid=None, payload_valid=None, null_equal=None):
+        """null_equal: per key column, IS NOT DISTINCT FROM (NULL = NULL, rows with such a NULL stay in the table)"""
         L = lib()
         self.keys = [np.ascontiguousarray(k) for k in keys]
         self.payload = [np.ascontiguousarray(p) for p in payload]
@@ -177,7 +180,8 @@ class HashTable:
         self._kc = _cols(list(zip(self.keys, kv)))
         self._pc = _cols(list(zip(self.payload, pv)))
         self.n_build_rows = n
-        self.h = L.orc_ht_build(self._kc, len(self.keys), self._pc, len(self.payload), n)
+        ne = (C.c_int * len(self.keys))(*[1 if x else 0 for x in (null_equal or [0] * len(self.keys))])
+        self.h = L.orc_ht_build2(self._kc, len(self.keys), self._pc, len(self.payload), n, ne)
         if not self.h:
             raise ValueError("orc_ht_build failed")
         self.pht = None

@@ -31,7 +31,8 @@ def oracle_joins(wl):
     joins = []
     for j in wl["joins"]:
         pv = [j.get("payload_valid", {}).get(n) for n in j["payload"].keys()]
-        ht = orc.HashTable(j["keys"], list(j["payload"].values()), key_valid=j.get("key_valid"), payload_valid=pv)
+        ht = orc.HashTable(j["keys"], list(j["payload"].values()), key_valid=j.get("key_valid"), payload_valid=pv,
+                           null_equal=[bool(f & 2) for f in j.get("key_flags", [])] or None)
         if j.get("perfect") is not None:
             ht.make_perfect(*j["perfect"])
         names = list(j["payload"].keys())
