@@ -828,8 +828,8 @@ def run_job_full(args, env, steps, warmup, with_cpu):
     shapes = jf.shapes()
     names_all = sorted(shapes)
     mine = [names_all[i] for i in pdist.shard_queries(len(names_all), world, rank)]
-    if os.environ.get("POLR_JOB_LIMIT"):
-        mine = mine[:int(os.environ["POLR_JOB_LIMIT"])]
+    if args.job_limit > 0:
+        mine = mine[:args.job_limit]
     tables = jf.Tables(scale=scale)
     dev_cols = {}
 
@@ -887,8 +887,12 @@ def run_job_full(args, env, steps, warmup, with_cpu):
         # (measured: running the pipelines side by side on shares of the device -- POLR_RUN_SHARE 4 / 8 / 16 -- is
         # 15-60 % slower than one after the other; a few fan-out heavy pipelines carry the pass, and they want the
         # whole device)
+        # (all on the context's stream: every pipeline's leader has a stream of its own, and full-size launches on
+        # different streams overlap at their edges -- the HIP events around a launch would then time the wait for the
+        # device, too)
         for c in cases:
-            capi.run_resident(c["mpxs"], c["ranges"], reset=True, finish=True)
+            capi.run_resident(c["mpxs"], c["ranges"], reset=True, finish=True,
+                              stream=None if args.own_streams else ctx.stream())
         if fetch:
             for c in cases:
                 try:
@@ -1197,6 +1201,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true")
+    ap.add_argument("--own-streams", action="store_true",
+                    help="job_full: every pipeline's launches on its leader's own stream (full-size launches side by side: a "
+                         "stress for the pool protocol, not a measurement)")
+    ap.add_argument("--job-limit", type=int, default=0, help="job_full: only the first N pipelines")
     ap.add_argument("--enable-lip", action="store_true",
                     help="PRAGMA enable_lip: the filters of the joins keyed by a source column thin the source chunks before "
                          "the multiplexer sees them (polr_pipeline_scan_filter_lip)")

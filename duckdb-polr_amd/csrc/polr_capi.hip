@@ -74,6 +74,14 @@ void polr_ctx_destroy(polr_ctx *ctx) {
 	}
 	hipSetDevice(ctx->device);
 	hipStreamSynchronize(ctx->stream);
+	for (auto &f : ctx->pool_launches) {
+		hipEventDestroy(f.done);
+	}
+	for (auto &e : ctx->pool_events_free) {
+		hipEventDestroy(e);
+	}
+	ctx->pool_launches.clear();
+	ctx->pool_events_free.clear();
 	hipStreamDestroy(ctx->stream);
 	// objects created on this context may outlive it (they hold references): what they still do -- free their
 	// device memory -- needs the device ordinal only; the default stream stands in for the destroyed one

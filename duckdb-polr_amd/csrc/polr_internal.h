@@ -25,6 +25,17 @@ struct polr_ctx {
 	std::atomic<int> refs {1};
 	bool closed = false; // polr_ctx_destroy was called: the stream is gone, the object lives on for its children
 	polr_pool_tuning tuning {}; // polr_ctx_set_pool_tuning (all zero: defaults)
+	// Pool launches in flight (polr_mpx.hip: order_pool_launch).  A pool launch is sized for the whole device -- or for the
+	// share of it its flags declare -- and its waves stay on the device until the run is over; two full-size launches on
+	// two streams would each hold part of the device with waves that wait for work only the rest of their own grid can
+	// unblock, and the watchdog of whichever router waits longest would give its run up.  The library orders them.
+	struct PoolLaunch {
+		hipStream_t stream;
+		hipEvent_t done;
+		uint32_t share;
+	};
+	std::vector<PoolLaunch> pool_launches;
+	std::vector<hipEvent_t> pool_events_free;
 };
 
 static inline polr_ctx *polr_ctx_retain(polr_ctx *ctx) {

@@ -285,6 +285,36 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 	return POLR_OK;
 }
 
+// A pool launch about to be enqueued on `st`, sized for 1 / share of the device: make `st` wait for the pool launches of
+// OTHER streams it cannot run beside -- all of them if this one takes the whole device, the full-size ones otherwise
+// (launches that each declared a share, POLR_RUN_SHARE, are the caller's to add up) -- and open the entry whose event the
+// caller records behind the launch.  Same-stream launches are ordered by the stream.
+static int order_pool_launch(polr_ctx *ctx, hipStream_t st, uint32_t share) {
+	std::vector<polr_ctx::PoolLaunch> keep;
+	for (auto &f : ctx->pool_launches) {
+		bool retire = f.stream == st; // (superseded: this stream's next launch carries the newer event)
+		if (!retire && (share <= 1 || f.share <= 1)) {
+			HIPCHK(ctx, hipStreamWaitEvent(st, f.done, 0));
+			retire = share <= 1; // (everything enqueued later waits for THIS launch, which waits for f)
+		}
+		if (retire) {
+			ctx->pool_events_free.push_back(f.done);
+		} else {
+			keep.push_back(f);
+		}
+	}
+	ctx->pool_launches.swap(keep);
+	hipEvent_t done;
+	if (!ctx->pool_events_free.empty()) {
+		done = ctx->pool_events_free.back();
+		ctx->pool_events_free.pop_back();
+	} else {
+		HIPCHK(ctx, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+	}
+	ctx->pool_launches.push_back({st, done, share});
+	return POLR_OK;
+}
+
 int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_info *info) {
 	POLR_ENTRY();
 	if (!p || !info) {
@@ -776,6 +806,13 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		dout = out->dev;
 		out->stats_valid = false;
 	}
+	// order this launch behind the pool launches of other streams it must not share the device with
+	{
+		int rc_o = order_pool_launch(ctx, st, share);
+		if (rc_o) {
+			return rc_o;
+		}
+	}
 	size_t ev = 0;
 	if (m0->timing) {
 		ev = m0->ev_used++;
@@ -800,6 +837,7 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 	if (m0->timing) {
 		HIPCHK(ctx, hipEventRecord(m0->ev_stop[ev], st));
 	}
+	HIPCHK(ctx, hipEventRecord(ctx->pool_launches.back().done, st)); // (the entry order_pool_launch made for this launch)
 	for (uint32_t i = 0; i < n; i++) {
 		ms[i]->pending_sync = true;
 	}
@@ -993,7 +1031,20 @@ int polr_mpx_finish_many(polr_mpx **ms, uint32_t n, polr_mpx_stats *stats) {
 		}
 	}
 	if (timed_out) {
-		POLR_FAIL(ctx, POLR_E_HIP, "run timed out waiting for its probe waves (results incomplete)");
+		// whose watchdog fired, and on what (the routers that saw it leave theirs in their pinned words)
+		std::string who;
+		for (uint32_t i = 0; i < n; i++) {
+			volatile uint32_t *w = (volatile uint32_t *)ms[i]->done_host;
+			if (w && w[4]) {
+				char buf[200];
+				snprintf(buf, sizeof(buf), "%s executor %u: slot %u, %u round(s) in flight, %llu of %llu arrival tokens (65536 per unit)",
+				         who.empty() ? ";" : ",", w[5], w[6], w[7], ((unsigned long long)w[11] << 32) | w[10],
+				         ((unsigned long long)w[9] << 32) | w[8]);
+				who += buf;
+				w[4] = 0;
+			}
+		}
+		POLR_FAIL(ctx, POLR_E_HIP, "run timed out waiting for its probe waves (results incomplete)%s", who.c_str());
 	}
 	return POLR_OK;
 }

@@ -66,6 +66,9 @@
 #define POLR_POOL_SHARDS 8
 #define POLR_POOL_HI_TUPLES 4096u // rounds up to this many tuples are latency-critical (exploration slices)
 #define POLR_POOL_HI_UNIT 64u // smallest unit of a small round (ring capacities are sized for it)
+#ifndef POLR_POOL_LOTTERY_PATIENCE
+#define POLR_POOL_LOTTERY_PATIENCE 64u // idle polls (> 100 us) after which a wave tries for ANY hi ticket, every 16th poll
+#endif
 #define POLR_POOL_KIND_WORK 1u
 #define POLR_POOL_KIND_EXIT 2u
 #define POLR_POOL_KIND_CONT 3u // shared work of the generic pipeline: tuples that wait in front of a stage (polr_poolg.hip)
@@ -319,11 +322,14 @@ __device__ __forceinline__ bool polr_pool_decode(unsigned long long g0, unsigned
 // read its entry (being written by the router that reserved it)
 __device__ __forceinline__ bool polr_pool_try_claim(POLR_GLOBAL unsigned long long *head, POLR_GLOBAL unsigned long long *tail,
                                                     POLR_GLOBAL PoolEntry *entries, uint32_t cap, uint32_t wave_in_ring,
-                                                    uint32_t lottery, unsigned long long timeout_ticks,
+                                                    uint32_t lottery, bool anybody, unsigned long long timeout_ticks,
                                                     unsigned long long &g0, unsigned long long &g1, uint32_t &tag) {
 	const unsigned long long hh = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const unsigned long long ht = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	if (hh >= ht || (((uint32_t)hh ^ wave_in_ring) & (lottery - 1u)) != 0) {
+	// the lottery keeps the compare-and-swap storm of a published unit small; `anybody` lifts it for a wave that has been
+	// idle for a while: the waves a ticket is meant for may not be on the device (another launch is holding their
+	// slots -- two full-size launches side by side), and a ticket nobody may take blocks every entry behind it
+	if (hh >= ht || (!anybody && (((uint32_t)hh ^ wave_in_ring) & (lottery - 1u)) != 0)) {
 		return false;
 	}
 	unsigned long long expect = hh;
@@ -353,6 +359,7 @@ struct PoolPoller {
 	POLR_GLOBAL PoolRingCtl *ctl;
 	POLR_GLOBAL PoolEntry *hi_q, *mid_q, *lo_q;
 	uint32_t lo_cap, hi_cap, wave_in_ring, lottery, idle_sleep;
+	uint32_t idle_polls;                      // polls since this wave last had a unit
 	unsigned long long lo_ticket, mid_ticket; // ~0ull: none
 	unsigned long long timeout_ticks;
 };
@@ -373,6 +380,7 @@ __device__ __forceinline__ void polr_pool_poller_init(PoolPoller &pp, PoolRun *r
 	pp.idle_sleep = idle_sleep;
 	pp.timeout_ticks = timeout_ticks;
 	pp.lo_ticket = pp.mid_ticket = ~0ull;
+	pp.idle_polls = 0;
 }
 
 // ONE look at the three queues (all lanes get the same answer): POLR_POLL_NONE, _WORK (u is the unit) or _LEAVE (an
@@ -386,7 +394,8 @@ __device__ __forceinline__ uint32_t polr_pool_poll(PoolPoller &pp, PoolUnit &u, 
 	if (lane == 0) {
 		// (1) units somebody waits for, small rounds first: only while a queue is not empty, never blocking
 		got = polr_pool_try_claim(&pp.ctl->hi_head, &pp.ctl->hi_tail, pp.hi_q, pp.hi_cap, pp.wave_in_ring, pp.lottery,
-		                          pp.timeout_ticks, g0, g1, tag)
+		                          pp.idle_polls >= POLR_POOL_LOTTERY_PATIENCE && (pp.idle_polls & 15u) == 15u, pp.timeout_ticks, g0, g1,
+		                          tag)
 		          ? 1u
 		          : 0u;
 		if (!got) {
@@ -422,8 +431,10 @@ __device__ __forceinline__ uint32_t polr_pool_poll(PoolPoller &pp, PoolUnit &u, 
 	}
 	got = __builtin_amdgcn_readfirstlane(got);
 	if (!got) {
+		pp.idle_polls++;
 		return POLR_POLL_NONE;
 	}
+	pp.idle_polls = 0;
 	g0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g0 >> 32)) << 32) |
 	     __builtin_amdgcn_readfirstlane((uint32_t)g0);
 	g1 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(g1 >> 32)) << 32) |
@@ -587,6 +598,10 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 	bool shadow_valid = false;               // scratch_lds holds the state as it will be after the last rehearsed round
 	bool shadow_ended = false;               // the rehearsal ran off the end of the source: nothing more to publish ahead
 	bool failed = false;
+	// what this router's own watchdog was waiting for when it fired (reported by polr_mpx_finish)
+	bool diag_timed = false;
+	unsigned long long diag_want = 0, diag_got = 0;
+	uint32_t diag_slot = 0, diag_fly = 0;
 	uint32_t rot = exec; // units of consecutive rounds start on different rings
 	// one routing step on whatever state sits in `lds` (the real one, or the shadow swapped in): the round it decides
 	auto route_here = [&](PoolRoundOut &r) -> bool {
@@ -657,11 +672,20 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 					uint32_t ab = __hip_atomic_load(&run->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					if (ab || wall_clock64() - t0 > rh.timeout_ticks) {
 						failed = true; // a probe wave is missing
+						if (!ab) { // (this router's own watchdog: say what it was waiting for, polr_mpx_finish reports it)
+							diag_want = want;
+							diag_slot = front_slot;
+							diag_fly = n_fly;
+							diag_timed = true;
+						}
 						break;
 					}
 				}
 			}
 			if (failed) {
+				if (diag_timed) {
+					diag_got = polr_pool_arrived(x.sync, front_slot, lane);
+				}
 				break;
 			}
 		}
@@ -796,6 +820,16 @@ __device__ __forceinline__ void polr_pool_router(const ResidentExec &x, PoolRun 
 			__hip_atomic_store(&run->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (host_words) {
 				host_words[2] = 1;
+			}
+			if (diag_timed && host_words) { // (the pinned words of THIS executor's multiplexer)
+				host_words[5] = exec;
+				host_words[6] = diag_slot;
+				host_words[7] = diag_fly;
+				host_words[8] = (uint32_t)diag_want;
+				host_words[9] = (uint32_t)(diag_want >> 32);
+				host_words[10] = (uint32_t)diag_got;
+				host_words[11] = (uint32_t)(diag_got >> 32);
+				host_words[4] = 1u;
 			}
 		}
 	}

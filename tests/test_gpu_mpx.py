@@ -384,3 +384,63 @@ def test_work_sharing_keeps_every_count(gpu_ctx, share_after):
     finally:
         gpu_ctx.set_pool_tuning()
     pipe.close()
+
+
+def test_full_size_runs_on_streams_of_their_own(gpu_ctx):
+    """pool launches of MANY pipelines, each sized for the whole device, enqueued without a synchronisation in between, every
+    pipeline's on the stream of its own leader.  Side by side each launch would hold part of the device with waves that wait
+    for work, and the watchdog of whichever router waited longest gave its run up: `python bench.py --workload job_full
+    --scale 0.2 --executors 4 --own-streams --job-limit 48 --steps 12 --no-kernel-events` ended in `run timed out waiting for
+    its probe waves` 8 times out of 8 (an executor's first exploration round: 0 of its 4 units in 4 s; a bulk round: 62 of
+    2 472 units missing) until the library ordered such launches itself (order_pool_launch, polr_mpx.hip: 2 of 2 clean).
+    This test is the small version of that command -- it keeps the path exercised; the bench command is the one that
+    showed the failure.  Every pipeline must finish, every pass, with the counts of a pass on one stream"""
+    from polr_amd import job_family as jf, host
+    shapes = jf.shapes()
+    tables = jf.Tables(scale=0.05)
+    cases = []
+    for name in sorted(shapes)[:32]:
+        wl = jf.workload(name, tables, shapes[name])
+        pn = list(wl["probe"]["cols"].keys())
+        paths = host.generate_join_orders("each_last_once", len(pn), [len(j["payload"]) for j in wl["joins"]],
+                                          wl["cond_left_index"], [len(j["keys"][0]) for j in wl["joins"]], max_join_orders=8)[0]
+        joins = capi.build_joins(gpu_ctx, wl, auto=True)
+        n_rows = len(wl["probe"]["cols"][pn[0]])
+        pipe = capi.Pipeline(gpu_ctx, list(wl["probe"]["cols"].values()), n_rows, joins, paths)
+        flt = wl["probe"].get("filter")
+        if flt:
+            _, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt], vector_size=1024)
+        else:
+            n_chunks = (n_rows + 1023) // 1024
+        e_n = max(1, min(4, n_chunks))
+        ms = []
+        for _e in range(e_n):
+            m = capi.DeviceMultiplexer(pipe, "adaptive_reinit", log_rounds=False)
+            if flt:
+                m.use_scan_chunks()
+            ms.append(m)
+        cases.append((pipe, ms, [((e * n_chunks) // e_n, ((e + 1) * n_chunks) // e_n) for e in range(e_n)], len(wl["joins"]),
+                      len(paths)))
+    def finish_all():
+        got = []
+        for _p, ms, _r, k, P in cases:
+            sts = capi.finish_many(ms)
+            got.append((sum(st["num_intermediates"] for st in sts), sum(st["stage_out"][p][k - 1] for st in sts for p in range(P))))
+        return got
+
+    try:
+        gpu_ctx.set_pool_tuning(watchdog_us=2_000_000)
+        for _p, ms, ranges, _k, _P in cases:
+            capi.run_resident(ms, ranges, reset=True, finish=True, stream=gpu_ctx.stream())  # (one stream: one after the other)
+        want = finish_all()
+        for _round in range(2):
+            for _pass in range(8):  # (nothing waits in between: hundreds of launches in flight on 32 streams)
+                for _p, ms, ranges, _k, _P in cases:
+                    capi.run_resident(ms, ranges, reset=True, finish=True)  # (no stream argument: the leader's own)
+            assert finish_all() == want
+    finally:
+        gpu_ctx.set_pool_tuning()
+    for pipe, ms, _r, _k, _P in cases:
+        for m in ms:
+            m.close()
+        pipe.close()
