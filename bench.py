@@ -839,7 +839,9 @@ def run_job_full(args, env, steps, warmup, with_cpu):
             dev_cols[key] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
         return dev_cols[key]
 
-    E = args.executors if args.executors > 0 else 8
+    # (executors per pipeline: 4 / 8 / 16 / 32 measured on the x0.2 instance: 61.6 / 49.8 / 44.7 / 43.7 ms of kernel time per
+    # pass -- 32 costs more host time per launch than it saves)
+    E = args.executors if args.executors > 0 else 16
     cases = []
     for name in mine:
         wl = jf.workload(name, tables, shapes[name])

@@ -1377,8 +1377,8 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 			const int32_t sc = joins[j].pred_src_col[c];
 			const uint32_t bc = joins[j].pred_build_col[c];
 			const uint32_t op = joins[j].pred_op[c];
-			if (op < POLR_CMP_NE || op > POLR_CMP_GE) {
-				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u condition %u: comparison %u (NE, LT, GT, LE, GE)", j, c, op);
+			if ((op < POLR_CMP_NE || op > POLR_CMP_GE) && op != POLR_CMP_STR_EQ) {
+				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u condition %u: comparison %u (NE, LT, GT, LE, GE, STR_EQ)", j, c, op);
 			}
 			if (bc >= ht->n_payload) {
 				POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: build column %u out of range", j, c, bc);
@@ -1396,7 +1396,12 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 				width = joins[sj].ht->payload[sc].width;
 			}
 			const OwnedCol &bcol = ht->kind == KIND_PERFECT ? ht->pcols[bc] : ht->payload[bc];
-			if (width != bcol.width || (width != 1 && width != 2 && width != 4 && width != 8)) {
+			if (op == POLR_CMP_STR_EQ) {
+				if (width != 16 || bcol.width != 16) {
+					POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: STR_EQ compares two columns of 16-byte string cells "
+					                               "(left %u bytes, right %u bytes)", j, c, width, bcol.width);
+				}
+			} else if (width != bcol.width || (width != 1 && width != 2 && width != 4 && width != 8)) {
 				POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: left side is %u bytes, right side %u bytes", j, c, width,
 				          bcol.width);
 			}

@@ -108,6 +108,40 @@ struct DevPath {
 // an extension record in global memory (StageDesc::ext): the descriptor every probe wave keeps in LDS stays small (the
 // per-wave LDS of the generic kernel is K descriptors + the queues, and it is staged again whenever the join order of a
 // unit differs from the last one's).
+// two string_t cells (16 bytes: length, then 12 inline characters or a 4-byte prefix + a pointer; string_type.hpp:23-28)
+// hold the same string -- the verifying condition of a VARCHAR join key (POLR_CMP_STR_EQ): the key itself is the 64-bit
+// hash the engine computed for the bucket, as in JoinHashTable::Hash + RowOperations::Match
+#define POLR_PRED_STR_EQ 8u
+__device__ __forceinline__ bool polr_str_cells_equal(const uint8_t *a_cell, const uint8_t *b_cell) {
+	const uint4 a = *(const uint4 *)a_cell, b = *(const uint4 *)b_cell;
+	if (a.x != b.x) {
+		return false;
+	}
+	if (a.x <= 12u) {
+		// (inline: compare the characters, not the padding)
+		const uint32_t n = a.x;
+		const uint32_t wa[3] = {a.y, a.z, a.w}, wb[3] = {b.y, b.z, b.w};
+		bool same = true;
+#pragma unroll
+		for (uint32_t i = 0; i < 3; i++) {
+			const uint32_t left = n > 4u * i ? n - 4u * i : 0u; // characters of this word that belong to the string
+			const uint32_t mask = left >= 4u ? 0xFFFFFFFFu : (left ? (1u << (8u * left)) - 1u : 0u);
+			same = same && ((wa[i] ^ wb[i]) & mask) == 0u;
+		}
+		return same;
+	}
+	if (a.y != b.y) { // (the prefix)
+		return false;
+	}
+	const uint8_t *pa = (const uint8_t *)(((uint64_t)a.w << 32) | a.z), *pb = (const uint8_t *)(((uint64_t)b.w << 32) | b.z);
+	for (uint32_t i = 4; i < a.x; i++) {
+		if (pa[i] != pb[i]) {
+			return false;
+		}
+	}
+	return true;
+}
+
 struct StageExt {
 	// every key column of the join, in packed form (KeyPack)
 	uint32_t key_width[POLR_NKEYS]; // of the column the PROBE side reads (a CAST'ed key: not the build column's)

@@ -225,6 +225,10 @@ __device__ __attribute__((noinline)) bool gen_preds_hold(const POLR_GLOBAL Stage
 		if ((lv && !lv[row]) || (rv && !rv[id])) {
 			ok = false;
 		}
+		if (d->pred_op[c] == POLR_PRED_STR_EQ) { // the strings behind a VARCHAR key's hash
+			ok = ok && polr_str_cells_equal(d->pred_data[c] + (uint64_t)row * 16u, d->pred_bdata[c] + (uint64_t)id * 16u);
+			continue;
+		}
 		const uint64_t l = gen_load_cell((const POLR_GLOBAL uint8_t *)d->pred_data[c] + (uint64_t)row * w, w, sx);
 		const uint64_t r = gen_load_cell((const POLR_GLOBAL uint8_t *)d->pred_bdata[c] + (uint64_t)id * w, w, sx);
 		bool h;

@@ -437,6 +437,10 @@ __device__ __attribute__((noinline)) bool preds_hold(const StageExt *d, uint32_t
 		if ((lv && !lv[row]) || (rv && !rv[id])) {
 			ok = false;
 		}
+		if (d->pred_op[c] == POLR_PRED_STR_EQ) { // the strings behind a VARCHAR key's hash
+			ok = ok && polr_str_cells_equal(d->pred_data[c] + (uint64_t)row * 16u, d->pred_bdata[c] + (uint64_t)id * 16u);
+			continue;
+		}
 		const uint64_t l = load_cell(d->pred_data[c] + (uint64_t)row * w, w, sx);
 		const uint64_t r = load_cell(d->pred_bdata[c] + (uint64_t)id * w, w, sx);
 		bool h;

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_ROOT, "libpolr_hip.so")
 
 MAX_JOINS, MAX_PATHS, MAX_KEYS = 8, 32, 4
 MAX_PREDS = 4
-CMP_PRED = {"<>": 1, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5}
+CMP_PRED = {"<>": 1, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5, "str_eq": 8}  # (8 = POLR_CMP_STR_EQ: string cells)
 COL_SIGNED, COL_DEVICE = 1, 2
 
 OK, E_NO_DEVICE, E_INVALID, E_UNSUPPORTED, E_HIP, E_DUPLICATE, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6
@@ -237,6 +237,16 @@ def string_cells(values):
             cells[i, 8:16] = np.frombuffer(np.uint64(base + off).tobytes(), dtype=np.uint8)
             off += len(v)
     return cells.reshape(-1).view("V16"), heap
+
+
+def string_hashes(values, bits=64):
+    """a 64-bit hash per string, as an engine hands over for a VARCHAR join key (JoinHashTable::Hash): the KEY column of
+    such a join on both sides; the strings themselves ride along as a "str_eq" condition.  bits < 64 keeps only the low bits
+    (tests: collisions on purpose, so that the verifying comparison has something to reject)"""
+    import xxhash
+    vals = [v.encode() if isinstance(v, str) else bytes(v) for v in values]
+    h = np.array([xxhash.xxh64_intdigest(v) for v in vals], dtype=np.uint64)
+    return h if bits >= 64 else (h & np.uint64((1 << bits) - 1))
 
 
 def _col_array(cols):
@@ -837,7 +847,10 @@ def build_joins(ctx, wl, auto=False):
             done = ht.finalize_perfect(*j["perfect"])
         if not done:
             ht.finalize_hash()
+        # conditions: (op, (src_join, src_col), build column NAME) -- a fixed-width payload column, or for "str_eq" one of the
+        # join's VARCHAR columns (their column numbers: string_payload_index)
         names = list(j["payload"].keys())
-        ht.preds = [(op, src, names.index(col)) for op, src, col in j.get("preds", [])]
+        ht.preds = [(op, src, names.index(col) if col in names else string_payload_index(j, col))
+                    for op, src, col in j.get("preds", [])]
         joins.append((ht, j["key_src"]))
     return joins

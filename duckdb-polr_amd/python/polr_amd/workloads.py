@@ -208,6 +208,84 @@ def key_semantics(n_fact=24_000, seed=SEED, cast=True):
 
 
 # -------------------------------------------------------------------------------------------------
+# VARCHAR join keys: the key column of such a join is the 64-bit hash the engine computes for the strings anyway
+# (JoinHashTable::Hash), the strings ride along as a verifying condition (POLR_CMP_STR_EQ) -- hash for the bucket, comparison
+# for the decision, as RowOperations::Match does.  fact.s = dim_s.k (strings of 3..40 characters, NULLs on both sides,
+# repeated build keys), dim_s.t = dim_t.k (a VARCHAR build column of an earlier join as the key), fact.c = dim_c.k.
+# hash_bits < 64 truncates the hashes: collisions on purpose.  "codes": the same joins on dictionary codes (what the
+# oracle, which has no strings, joins on -- the same equalities).
+# -------------------------------------------------------------------------------------------------
+def varchar_keys(n_fact=20_000, seed=SEED, hash_bits=12):
+    from . import capi as _capi
+    rng = _rng(seed, 8)
+
+    def word(i, salt):
+        # (short and long strings: inline cells and heap cells; common prefixes among the long ones)
+        base = "k%d" % i if i % 3 else "a-rather-long-key-with-a-common-prefix-%06d" % i
+        return (base + ("/" + salt if salt else "")).encode()
+
+    n_s, n_t, n_c = 1_500, 300, 700
+    t_vals = [word(i, "t") for i in range(n_t)]
+    s_vals = [word(i, "") for i in range(n_s)]
+    s_rows = list(range(n_s)) + [int(x) for x in rng.integers(0, n_s, 200)]      # 200 repeated build keys
+    s_rows = [s_rows[i] for i in rng.permutation(len(s_rows))]
+    dim_s_k = [s_vals[i] for i in s_rows]
+    dim_s_kvalid = (rng.random(len(s_rows)) < 0.97).astype(np.uint8)
+    dim_s_t = [t_vals[int(x)] if x < n_t else word(int(x), "miss") for x in rng.integers(0, n_t + 60, len(s_rows))]
+    dim_t_k = [t_vals[i] for i in rng.permutation(n_t)]
+    c_keys = (np.arange(n_c, dtype=np.int32) * 2 + 10).astype(np.int32)
+    fs = [s_vals[int(x)] if x < n_s else word(int(x), "none") for x in rng.integers(0, n_s + 300, n_fact)]
+    fs_valid = (rng.random(n_fact) < 0.95).astype(np.uint8)
+    fc = np.where(rng.random(n_fact) < 0.75, c_keys[rng.integers(0, n_c, n_fact)], 3).astype(np.int32)
+    h = lambda vals: _capi.string_hashes(vals, hash_bits)  # noqa: E731
+    fact = {"id": np.arange(n_fact, dtype=np.int32), "c": fc, "hs": h(fs)}
+    js = {"name": "dim_s", "keys": [h(dim_s_k)], "key_names": ["hk"], "key_valid": [dim_s_kvalid],
+          "payload": {"ps": (np.arange(len(s_rows)) % 17).astype(np.int32), "ht": h(dim_s_t)},
+          "strings": {"k": dim_s_k, "t": dim_s_t}, "key_src": [(-1, 2)], "perfect": None,
+          # (left side: the probe table's VARCHAR column "s" = probe column 3, behind the three fixed-width ones)
+          "preds": [("str_eq", (-1, 3), "k")]}
+    jt = {"name": "dim_t", "keys": [h(dim_t_k)], "key_names": ["hk"],
+          "payload": {"pt": (np.arange(n_t) * 3 % 11).astype(np.int32)}, "strings": {"k": dim_t_k},
+          "key_src": [(0, 1)], "perfect": None,
+          # (left side: dim_s's VARCHAR payload column "t": its payload columns are ps, ht, then the strings k, t)
+          "preds": [("str_eq", (0, 3), "k")]}
+    jc = {"name": "dim_c", "keys": [c_keys[rng.permutation(n_c)]], "key_names": ["k"], "payload": {"pc": None},
+          "key_src": [(-1, 1)], "perfect": (int(c_keys.min()), int(c_keys.max()))}
+    jc["payload"]["pc"] = (jc["keys"][0] % 97).astype(np.int32)
+    wl = {"name": "varchar_keys", "probe": {"name": "fact", "cols": fact, "strings": {"s": fs},
+                                            "valid": {"hs": fs_valid}, "string_valid": {"s": fs_valid}},
+          "joins": [js, jt, jc],
+          # BoundReference index of every join's probe-side key in the reference's layout: fact(id, c, s), then dim_s's
+          # columns (k, ps, t), dim_t's ...
+          "cond_left_index": [[2], [5], [1]]}
+    # ---- the same joins on dictionary codes (oracle)
+    words = sorted(set(fs) | set(dim_s_k) | set(dim_s_t) | set(dim_t_k))
+    code = {w: i for i, w in enumerate(words)}
+    enc = lambda vals: np.array([code[v] for v in vals], dtype=np.int32)  # noqa: E731
+    wl["codes"] = {
+        "probe": {"name": "fact", "cols": {"id": fact["id"], "c": fc, "s": enc(fs)}, "valid": {"s": fs_valid}},
+        "joins": [{"name": "dim_s", "keys": [enc(dim_s_k)], "key_valid": [dim_s_kvalid],
+                   "payload": {"ps": js["payload"]["ps"], "t": enc(dim_s_t)}, "key_src": [(-1, 2)], "perfect": None},
+                  {"name": "dim_t", "keys": [enc(dim_t_k)], "payload": {"pt": jt["payload"]["pt"]}, "key_src": [(0, 1)],
+                   "perfect": None},
+                  {"name": "dim_c", "keys": jc["keys"], "payload": {"pc": jc["payload"]["pc"]}, "key_src": [(-1, 1)],
+                   "perfect": jc["perfect"]}]}
+    # ---- and for the reference: VARCHAR columns as they are, NULLs as a sentinel set by UPDATEs after the load
+    null = b"\x01NULL"
+    t_fact = {"id": fact["id"], "c": fc, "s": [v if ok else null for v, ok in zip(fs, fs_valid)]}
+    t_s = {"k": [v if ok else null for v, ok in zip(dim_s_k, dim_s_kvalid)], "ps": js["payload"]["ps"], "t": dim_s_t}
+    wl["ref"] = {
+        "tables": {"fact": t_fact, "dim_s": t_s, "dim_t": {"k": dim_t_k, "pt": jt["payload"]["pt"]},
+                   "dim_c": {"k": jc["keys"][0], "pc": jc["payload"]["pc"]}},
+        "pk": {},
+        "settings": ["UPDATE fact SET s = NULL WHERE s = '\x01NULL'", "UPDATE dim_s SET k = NULL WHERE k = '\x01NULL'",
+                     "SET disabled_optimizers TO 'join_order,statistics_propagation'"],
+        "query": "SELECT COUNT(*) FROM fact JOIN dim_s ON fact.s = dim_s.k JOIN dim_t ON dim_s.t = dim_t.k "
+                 "JOIN dim_c ON fact.c = dim_c.k"}
+    return wl
+
+
+# -------------------------------------------------------------------------------------------------
 # heavy fan-out (JOB's cast_info / movie_info style duplicates)
 # -------------------------------------------------------------------------------------------------
 def fanout(n_fact=40_000, seed=SEED):

@@ -94,7 +94,8 @@ int polr_ctx_get_stream(polr_ctx *ctx, void **stream);
 typedef struct polr_pool_tuning {
 	uint32_t device_share; /* size every run's grid for 1/device_share of the device (1..16); 0: as the run's flags say */
 	uint32_t units_x;      /* a big round is cut into about units_x x probe waves / routing executors units (1..4; default 4) */
-	uint32_t hi_unit;      /* tuples per unit of a small round: 64..1024, a multiple of 64 (default: 1024 flat, 256 generic) */
+	uint32_t hi_unit;      /* tuples per unit of a small round: 64..1024, a multiple of 64 (default: 1024 flat; generic 64,
+	                          with more than 64 executors 256) */
 	uint32_t hi_lottery;   /* power of two: wave w of a ring tries for hi ticket t only if w % lottery == t % lottery */
 	uint32_t hi_tuples_p1; /* 1 + the size up to which a round counts as small (default 4096); 0: default */
 	uint32_t idle_sleep;   /* 16: an idle probe wave's back-off stays at s_sleep 16 (default 64) */
@@ -219,7 +220,7 @@ typedef struct polr_join_desc {
 	 * never matches; both sides must have the same width.  The join's output (and its share of the intermediates)
 	 * are the pairs that pass. */
 	uint32_t n_preds;
-	uint32_t pred_op[POLR_MAX_PREDS]; /* POLR_CMP_NE .. POLR_CMP_GE */
+	uint32_t pred_op[POLR_MAX_PREDS]; /* POLR_CMP_NE .. POLR_CMP_GE, POLR_CMP_STR_EQ */
 	int32_t pred_src_join[POLR_MAX_PREDS];
 	int32_t pred_src_col[POLR_MAX_PREDS];
 	uint32_t pred_build_col[POLR_MAX_PREDS];
@@ -257,7 +258,13 @@ int polr_pipeline_launch_info(polr_pipeline *p, int materialize, polr_launch_inf
  * down on this path (POLR_E_UNSUPPORTED would be the caller's: keep them in a host filter). */
 enum {
 	POLR_CMP_EQ = 0, POLR_CMP_NE = 1, POLR_CMP_LT = 2, POLR_CMP_GT = 3, POLR_CMP_LE = 4, POLR_CMP_GE = 5,
-	POLR_CMP_IS_NULL = 6, POLR_CMP_IS_NOT_NULL = 7
+	POLR_CMP_IS_NULL = 6, POLR_CMP_IS_NOT_NULL = 7,
+	/* join conditions only: two columns of 16-byte string cells (string_t) hold the same string.  This is how a VARCHAR
+	 * join key arrives: the KEY is the 64-bit hash the engine computes for it anyway (JoinHashTable::Hash,
+	 * join_hashtable.cpp:141-155 -- an 8-byte key column on both sides), the strings themselves are this condition --
+	 * the hash finds the candidates, the comparison decides, as RowOperations::Match does behind the bucket chain
+	 * (row_match.cpp).  The cells' heaps: polr_ht_set_payload_heap / polr_pipeline_set_probe_heap. */
+	POLR_CMP_STR_EQ = 8
 };
 typedef struct polr_scan_filter {
 	uint32_t col;     /* probe-table column */
