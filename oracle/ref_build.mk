@@ -82,5 +82,14 @@ $(LIB): $(ALL_OBJ)
 $(DRIVER): $(HERE)ref_driver.cpp $(LIB)
 	$(CXX) -std=c++11 -O2 -pthread $(INC) $(DEFS) $< -o $@ -L$(OUT) -lduckdb_ref -Wl,-rpath,'$$ORIGIN' -ldl
 
+# the duckdb:: adapter of INTEGRATION.md section 2 (duckdb-polr_amd/host/duckdb_adapter/) run against the reference's own
+# JoinHashTable: tests/conformance/adapter_main.cpp, linked against the reference and the device library
+ADAPTER := $(OUT)/adapter_test
+REPO    := $(abspath $(HERE)..)
+adapter: $(ADAPTER)
+$(ADAPTER): $(REPO)/tests/conformance/adapter_main.cpp $(REPO)/duckdb-polr_amd/host/duckdb_adapter/polr_duckdb_adapter.hpp $(LIB)
+	$(CXX) -std=c++11 -O2 -pthread $(INC) $(DEFS) -I$(REPO)/include -I$(REPO)/duckdb-polr_amd/host $< -o $@ \
+	    -L$(OUT) -lduckdb_ref -L$(REPO)/duckdb-polr_amd -lpolr_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../duckdb-polr_amd' -ldl
+
 clean:
 	rm -rf $(OUT)
