@@ -357,7 +357,8 @@ int polr_ht_upload_rows(polr_ctx *ctx, const void *rows, uint64_t n_rows, uint32
 		col.flags = col_flags ? (col_flags[c] & POLR_COL_SIGNED) : 0;
 		col.owned = true;
 		rc = dev_alloc(ctx, (void **)&col.data, n_rows * col.width, &ht->device_bytes);
-		if (!rc && c >= n_keys) {
+		if (!rc) {
+			// (key columns too: a table whose condition is IS NOT DISTINCT FROM keeps its NULL-key rows, join_hashtable.cpp:182)
 			rc = dev_alloc(ctx, (void **)&col.valid, n_rows, &ht->device_bytes);
 		}
 		if (!rc) {

@@ -102,13 +102,14 @@ inline void PolrFlatten(Vector &v, idx_t count, std::vector<uint8_t> &cells, std
 inline polr_pipeline *PolrMakeProbePipeline(polr_ctx *ctx, JoinHashTable &ht, polr_ht *dht) {
 	const idx_t n_keys = ht.condition_types.size();
 	std::vector<std::vector<uint8_t>> zeros;
+	std::vector<uint8_t> ones(STANDARD_VECTOR_SIZE, 1); // (a column that will carry NULLs is created with a validity array)
 	std::vector<polr_col> cols;
 	for (idx_t c = 0; c < n_keys; c++) {
 		const idx_t w = GetTypeIdSize(ht.condition_types[c].InternalType());
 		zeros.emplace_back(STANDARD_VECTOR_SIZE * w, 0);
 		polr_col pc;
 		pc.data = zeros.back().data();
-		pc.valid = nullptr;
+		pc.valid = ones.data();
 		pc.width = (uint32_t)w;
 		pc.flags = PolrColFlags(ht.condition_types[c]);
 		cols.push_back(pc);
