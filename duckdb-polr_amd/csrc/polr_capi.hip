@@ -1378,8 +1378,8 @@ int polr_pipeline_create(polr_ctx *ctx, const polr_col *probe_cols, uint32_t n_p
 			const int32_t sc = joins[j].pred_src_col[c];
 			const uint32_t bc = joins[j].pred_build_col[c];
 			const uint32_t op = joins[j].pred_op[c];
-			if ((op < POLR_CMP_NE || op > POLR_CMP_GE) && op != POLR_CMP_STR_EQ) {
-				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u condition %u: comparison %u (NE, LT, GT, LE, GE, STR_EQ)", j, c, op);
+			if (op > POLR_CMP_GE && op != POLR_CMP_STR_EQ) {
+				POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "join %u condition %u: comparison %u (EQ, NE, LT, GT, LE, GE, STR_EQ)", j, c, op);
 			}
 			if (bc >= ht->n_payload) {
 				POLR_FAIL(ctx, POLR_E_INVALID, "join %u condition %u: build column %u out of range", j, c, bc);

@@ -234,6 +234,7 @@ __device__ __attribute__((noinline)) bool gen_preds_hold(const POLR_GLOBAL Stage
 		bool h;
 		if (w == 8 && !sx) {
 			switch (d->pred_op[c]) {
+			case 0: h = l == r; break; // (POLR_CMP_EQ: the verifying comparison behind a hashed composite key)
 			case 1: h = l != r; break;
 			case 2: h = l < r; break;
 			case 3: h = l > r; break;
@@ -243,6 +244,7 @@ __device__ __attribute__((noinline)) bool gen_preds_hold(const POLR_GLOBAL Stage
 		} else {
 			const int64_t a = (int64_t)l, b = (int64_t)r; // (narrow unsigned values are zero-extended: same order)
 			switch (d->pred_op[c]) {
+			case 0: h = a == b; break;
 			case 1: h = a != b; break;
 			case 2: h = a < b; break;
 			case 3: h = a > b; break;

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_ROOT, "libpolr_hip.so")
 
 MAX_JOINS, MAX_PATHS, MAX_KEYS = 8, 32, 4
 MAX_PREDS = 4
-CMP_PRED = {"<>": 1, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5, "str_eq": 8}  # (8 = POLR_CMP_STR_EQ: string cells)
+CMP_PRED = {"=": 0, "==": 0, "<>": 1, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5, "str_eq": 8}  # (8 = POLR_CMP_STR_EQ: string cells)
 COL_SIGNED, COL_DEVICE = 1, 2
 
 OK, E_NO_DEVICE, E_INVALID, E_UNSUPPORTED, E_HIP, E_DUPLICATE, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6

@@ -220,7 +220,10 @@ typedef struct polr_join_desc {
 	 * never matches; both sides must have the same width.  The join's output (and its share of the intermediates)
 	 * are the pairs that pass. */
 	uint32_t n_preds;
-	uint32_t pred_op[POLR_MAX_PREDS]; /* POLR_CMP_NE .. POLR_CMP_GE, POLR_CMP_STR_EQ */
+	uint32_t pred_op[POLR_MAX_PREDS]; /* POLR_CMP_EQ .. POLR_CMP_GE, POLR_CMP_STR_EQ.  EQ is the verifying comparison of a
+	                                     composite key the engine hands over HASHED (an 8-byte key column = its hash of the
+	                                     key columns, one EQ condition per column): the way in for composite keys whose
+	                                     value ranges do not pack into 64 bits */
 	int32_t pred_src_join[POLR_MAX_PREDS];
 	int32_t pred_src_col[POLR_MAX_PREDS];
 	uint32_t pred_build_col[POLR_MAX_PREDS];

@@ -335,6 +335,64 @@ def test_composite_key_wider_than_64_bits_is_refused(gpu_ctx):
     assert e.value.code == capi.E_UNSUPPORTED
 
 
+def test_wide_composite_key_hashed_and_verified(gpu_ctx):
+    """a composite key whose value ranges do not pack into 64 bits (three full-range 32-bit columns: refused in packed form,
+    see above) arrives HASHED: the key column on both sides is a 64-bit hash of the three columns (here cut to 14 bits: most
+    candidates are collisions), and one POLR_CMP_EQ condition per column decides -- JoinHashTable::Hash + RowOperations::Match
+    with the hash computed by the engine.  Per-round path kernel and pool launch, against the oracle's three-key join; a
+    second join so that the hashed one also runs at position 1"""
+    rng = np.random.default_rng(45)
+    nb, n = 5000, 20000
+    bk = [rng.integers(-2**31, 2**31 - 1, nb).astype(np.int32) for _ in range(3)]
+    src = rng.integers(0, nb, n)
+    pk = [np.where(rng.random(n) < 0.7, bk[c][src], rng.integers(-2**31, 2**31 - 1, n)).astype(np.int32) for c in range(3)]
+    pk[2] = np.where(rng.random(n) < 0.1, pk[2] + 1, pk[2]).astype(np.int32)  # near misses: two of three columns equal
+    dup = rng.integers(0, nb, 600)
+    for c in range(3):
+        bk[c] = np.concatenate([bk[c], bk[c][dup]])  # repeated keys
+    nb = len(bk[0])
+
+    def h(cols):
+        x = (cols[0].astype(np.int64) * 1000003) ^ (cols[1].astype(np.int64) * 998244353) ^ (cols[2].astype(np.int64) * 19260817)
+        return (x.astype(np.uint64) >> np.uint64(7)) & np.uint64((1 << 14) - 1)
+
+    pay = (np.arange(nb) % 997).astype(np.int32)
+    d = np.arange(0, 64, dtype=np.int32)
+    pd = rng.integers(0, 80, n).astype(np.int32)
+    paths = [[0, 1], [1, 0]]
+    # oracle: the plain three-key join
+    oj = [orc.JoinSpec(orc.HashTable(bk, [pay]), [(-1, 0), (-1, 1), (-1, 2)]), orc.JoinSpec(orc.HashTable([d], [d]), [(-1, 3)])]
+    ocols = pk + [pd]
+    # device: hashed key + three verifying equalities (the build columns ride along as payload columns 1..3)
+    ght = capi.HashTable.from_columns(gpu_ctx, [h(bk)], [pay] + bk)
+    ght.preds = [("=", (-1, c), 1 + c) for c in range(3)]
+    ght.finalize_hash()
+    gd = capi.HashTable.from_columns(gpu_ctx, [d], [d])
+    gd.finalize_hash()
+    gcols = pk + [pd, h(pk)]
+    pipe = capi.Pipeline(gpu_ctx, gcols, n, [(ght, [(-1, 4)]), (gd, [(-1, 3)])], paths)
+    for p in range(2):
+        ref = orc.run_pipeline(ocols, oj, [paths[p]], routing="default_path")
+        want = ref["out_rows"]
+        out = capi.Output(pipe, 1024, 8192)
+        counts = pipe.probe_rounds([(0, n, p, 1)], out=out)
+        assert int(counts.sum()) == ref["num_intermediates"]
+        ids = out.fetch_ids()
+        assert np.array_equal(ids[np.lexsort(ids.T[::-1])], want[np.lexsort(want.T[::-1])]), "path %d" % p
+        rpipe = capi.Pipeline(gpu_ctx, gcols, n, [(ght, [(-1, 4)]), (gd, [(-1, 3)])], [paths[p], paths[1 - p]])
+        mpx = capi.DeviceMultiplexer(rpipe, "default_path", chunk_size=1024)
+        rout = capi.Output(rpipe, 1024, 8192)
+        capi.run_resident([mpx], [(0, (n + 1023) // 1024)], out=rout, reset=True, finish=True)
+        st = mpx.finish()
+        assert st["num_intermediates"] == ref["num_intermediates"]
+        rids = rout.fetch_ids()
+        assert np.array_equal(rids[np.lexsort(rids.T[::-1])], want[np.lexsort(want.T[::-1])]), "resident, path %d" % p
+        mpx.close()
+        rpipe.close()
+    assert len(want) > 5000
+    pipe.close()
+
+
 def test_non_equality_conditions(gpu_ctx):
     """join conditions other than equalities (RowOperations::Match, row_match.cpp:59-119): every operator, signed and
     unsigned sides, 64-bit unsigned values beyond 2^63, NULLs on either side, and a left side that is a build column of
