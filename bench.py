@@ -202,8 +202,8 @@ def cpu_baseline_ssb(inst, query, routing, args, sample_rows, dev=None, shipped=
         settings = list(ref["settings"]) + ["SET multiplexer_routing TO '%s'" % routing,
                                             "SET join_enumerator TO '%s'" % args.enumerator_name,
                                             "SET max_join_orders TO %d" % args.max_join_orders]
-        # (the GROUP BY form has been seen to end in "vector::reserve" on 256-thread hosts: its ladder stops at 32 threads,
-        # beyond which the reference's POLAR pipeline has not returned a right answer on any workload anyway)
+        # (the GROUP BY form's ladder stops at 32 threads: beyond, the reference's POLAR pipeline has not returned a right
+        # answer on any workload, and here only the NUMBER of groups stands in for COUNT(*) in the validity check)
         ladder = [t for t in thread_ladder() if t <= 32] if shipped else None
         runs = reference_runs(ref["tables"], ref["pk"], ref["query"], settings, n, repeat=3, threads=ladder)
         ref_count = runs.get(1, (None, None))[1]
@@ -1113,17 +1113,20 @@ def run_q41_shipped(args, env, steps, warmup, with_cpu):
     inter = sum(st["num_intermediates"] for st in stats)
     cpu = None
     if with_cpu:
+        # (the reference runs what the device ran: the SAMPLE enumerator -- run_case leaves the enumerator of ITS workload
+        # in args, and each_last_once with max_join_orders below the join count ends the reference in "vector::reserve")
+        args.enumerator_name = "sample"
         try:
-            cpu = cpu_baseline_ssb(inst, query, routing, args, min(args.cpu_sample_rows, 16_000_000), dev=dev, shipped=True)
+            cpu = cpu_baseline_ssb(inst, query, routing, args, min(args.cpu_sample_rows, args.shipped_sample_rows), dev=dev,
+                                   shipped=True)
             if cpu:
                 cpu["value"] = round(cpu["value"], 1)
         except Exception as e:
-            # (seen on the 256-thread GPU hosts: the reference answers its own shipped SQL with "Invalid Error:
-            # vector::reserve" at every thread count -- on the 8-core build container it runs it, at 57 M tuples/s on one
-            # thread.  The COUNT(*) form of the same pipeline on the same samples is timed instead and labelled as such.)
+            # (should the reference fail on the shipped select list: the COUNT(*) form of the same pipeline on the same
+            # samples is timed instead and labelled as such)
             err = str(e)[-400:]
             try:
-                cpu = cpu_baseline_ssb(inst, query, routing, args, min(args.cpu_sample_rows, 16_000_000), dev=dev)
+                cpu = cpu_baseline_ssb(inst, query, routing, args, min(args.cpu_sample_rows, args.shipped_sample_rows), dev=dev)
                 cpu["value"] = round(cpu["value"], 1)
                 cpu["sink"] = "COUNT(*) -- the reference failed on the shipped select list on this host: " + err
             except Exception as e2:
@@ -1203,6 +1206,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true")
+    ap.add_argument("--shipped-sample-rows", type=int, default=16_000_000,
+                    help="rows per sample of the CPU leg of the 'Q4.1 as shipped' sub-record")
     ap.add_argument("--own-streams", action="store_true",
                     help="job_full: every pipeline's launches on its leader's own stream (full-size launches side by side: a "
                          "stress for the pool protocol, not a measurement)")
@@ -1278,6 +1283,12 @@ def main():
     if knobs:
         ctx.set_pool_tuning(**knobs)
     env = {"torch": torch, "dist": dist, "dev": dev, "ctx": ctx, "world": world, "rank": rank}
+    if args.workload == "ssb_skew_q41_shipped":  # (the sub-record of the default line on its own)
+        args.enumerator_name = "sample" if args.enumerator == "auto" else args.enumerator
+        head = run_q41_shipped(args, env, min(args.steps, 10), min(args.warmup, 2), with_cpu=not args.no_cpu_baseline)
+        print(json.dumps(head))
+        ctx.close()
+        return
     if args.workload == "job_full":
         head = run_job_full(args, env, args.steps, args.warmup, with_cpu=world == 1 and not args.no_cpu_baseline)
         if rank == 0:

@@ -184,6 +184,9 @@ int polr_bcast_build(polr_comm *comm, polr_ht **ht, int root, void *stream) {
 	if (is_root) {
 		if (!*ht || (*ht)->kind == KIND_NONE) {
 			fail_local(POLR_E_INVALID, "broadcast root has no finalized build side");
+		} else if (!(*ht)->heaps.empty()) {
+			// (the cells of a VARCHAR column hold addresses of the root's heap)
+			fail_local(POLR_E_UNSUPPORTED, "a build side with VARCHAR columns (string heaps) is not broadcast: upload it on every rank");
 		} else {
 			uint64_t mb = 0;
 			uint32_t nb = 0;

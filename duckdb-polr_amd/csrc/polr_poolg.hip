@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * POOLG_WAVES, 4) void polr_pool_gen_kernel(cons
 	PoolRun rh;
 	pool_load_run(run, rh);
 	if (blockIdx.x < rh.n_router_blocks) {
-		pool_router_wave(execs, run, rh, k, 256, lds, lds_per_wave);
+		pool_router_wave(execs, run, rh, k, 64, lds, lds_per_wave); // (units of big rounds: multiples of 64 tuples)
 		return;
 	}
 	// probe wave g of the pool serves ring g % n_rings (dealt wave by wave: every ring the same number of waves)

@@ -178,7 +178,17 @@ int main(int argc, char **argv) {
 		return 1;
 	}
 
-	DuckDB db(nullptr);
+	// POLR_REF_OPEN_THREADS=<n>: open the database with at most n worker threads (DBConfig::maximum_threads) instead of one
+	// per hardware thread.  (On the 256-thread hosts of the GPU boxes the reference's GROUP BY plans end in "Invalid Error:
+	// vector::reserve" when the instance was OPENED with 256 threads, whatever `SET threads` says afterwards.)
+	DBConfig config;
+	if (const char *open_threads = getenv("POLR_REF_OPEN_THREADS")) {
+		const long n = atol(open_threads);
+		if (n > 0) {
+			config.options.maximum_threads = (idx_t)n;
+		}
+	}
+	DuckDB db(nullptr, &config);
 	Connection con(db);
 
 	std::string line, tname;
