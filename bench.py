@@ -650,7 +650,7 @@ def run_case(name, scale, args, env, steps, warmup, with_cpu):
                    "max_join_orders": int(args.max_join_orders), "executors_per_gpu": int(E), "n_gpus": int(world)}
             roof["pmc_signature"] = sig
             pmc, pmc_file = find_pmc_summary(sig)
-            if pmc and not args.morsels and not device_scan:
+            if pmc and not args.morsels:  # (the PMC passes count the pool kernel's dispatches only: a device scan before it does not matter)
                 # REPLAYED, not measured in this run: HBM bytes per launch of the same command's separate rocprofv3
                 # --pmc passes (FETCH_SIZE, WRITE_SIZE), FETCH_SIZE corrected as calibrated for this kernel's access
                 # patterns on gfx950 (profiles/r02_fetch_size_calibration.json)
