@@ -1073,7 +1073,8 @@ def run_q41_shipped(args, env, steps, warmup, with_cpu):
     mpxs = [capi.DeviceMultiplexer(pipe, routing, chunk_size=V, regret_budget=args.regret_budget,
                                    init_tuple_count=args.init_tuple_count, log_rounds=False) for _ in range(E)]
     ranges = [((e * n_chunks) // E, ((e + 1) * n_chunks) // E) for e in range(E)]
-    out = capi.Output(pipe, 1024, 32768)
+    fused = not args.two_kernel_sink
+    out = capi.Output(pipe, 1024, 64 if fused else 32768)
     cn = wl0["joins"][0]["payload"]["c_nation"]
     dy = wl0["joins"][3]["payload"]["d_year"]
     keys = [(3, 0, int(dy.min()), int(dy.max()) - int(dy.min()) + 1), (0, 0, int(cn.min()), int(cn.max()) - int(cn.min()) + 1)]
@@ -1082,10 +1083,14 @@ def run_q41_shipped(args, env, steps, warmup, with_cpu):
 
     ctx_stream = ctx.stream()  # the run goes on the context's stream: in line with the reset before, the aggregate behind
 
+    if fused:
+        out.fuse_grouped(keys, specs)  # the GROUP BY inside the run: the last join folds its survivors into the group cells
+
     def step():
         out.reset()
         capi.run_resident(mpxs, ranges, out=out, reset=True, finish=True, stream=ctx_stream)
-        result[0] = out.aggregate_grouped(keys, specs)  # (reads the group cells back: synchronises)
+        # (reads the group cells back: synchronises)
+        result[0] = out.fused_result(stream=ctx_stream) if fused else out.aggregate_grouped(keys, specs)
 
     for _ in range(warmup):
         step()
@@ -1138,14 +1143,19 @@ def run_q41_shipped(args, env, steps, warmup, with_cpu):
                                   "part / date, sink SUM(lo_revenue - lo_supplycost) GROUP BY d_year, c_nation "
                                   "(benchmark/ssb-skew/queries/q4-1.sql; c_nation as its code)" % (scale, n),
                       "routing": routing, "join_enumerator": "sample", "max_join_orders": 3, "join_orders": paths.tolist(),
-                      "executors_per_gpu": E, "sink": "perfect-hash GROUP BY on the device (polr_out_aggregate_grouped) over "
-                                                      "the row ids the flat pool launch emits",
+                      "executors_per_gpu": E,
+                      "sink": ("perfect-hash GROUP BY FUSED into the run (polr_out_fuse_grouped): the last join folds its "
+                               "survivors into the group cells, no row id is written") if fused else
+                              ("perfect-hash GROUP BY on the device (polr_out_aggregate_grouped) over the row ids the flat "
+                               "pool launch emits"),
                       "launch": "flat pipeline, emitting" if info.get("flat") else "generic pipeline, emitting"},
            "count_star": count_star, "groups": len(groups), "rows_dropped_by_the_group_domain": int(dropped),
            "profit_checksum": int(sum(groups.values())), "total_intermediates": int(inter),
            "pool_kernel_ms_per_step": round(kernel_ms, 4),
-           "timed_region": {"gpu": "output cursor reset + routing and probing of every source chunk + row-id emission of the "
-                                   "join result + grouped aggregate; the group cells are read back every step",
+           "timed_region": {"gpu": ("reset of the group cells + routing and probing of every source chunk with the aggregate "
+                                    "inside the launch; the group cells are read back every step") if fused else
+                                   ("output cursor reset + routing and probing of every source chunk + row-id emission of the "
+                                    "join result + grouped aggregate; the group cells are read back every step"),
                             "cpu": "the reference's whole pipeline on the same SQL: scan + joins + its perfect-hash aggregate"},
            "cpu_baseline": cpu, "launch_info": info}
     if cpu and cpu.get("value"):
@@ -1208,6 +1218,8 @@ def main():
     ap.add_argument("--no-sub-records", action="store_true")
     ap.add_argument("--shipped-sample-rows", type=int, default=16_000_000,
                     help="rows per sample of the CPU leg of the 'Q4.1 as shipped' sub-record")
+    ap.add_argument("--two-kernel-sink", action="store_true",
+                    help="'Q4.1 as shipped': row ids + polr_out_aggregate_grouped instead of the GROUP BY fused into the run")
     ap.add_argument("--own-streams", action="store_true",
                     help="job_full: every pipeline's launches on its leader's own stream (full-size launches side by side: a "
                          "stress for the pool protocol, not a measurement)")

@@ -25,19 +25,6 @@ struct AggPartial {
 	unsigned long long count; // rows that took part (non-NULL; all rows for COUNT(*))
 };
 
-struct DevAgg {
-	DevCol src;
-	uint32_t slot; // 0: probe row ids, 1 + j: build row ids of join j
-	uint32_t fn;
-};
-
-#define POLR_MAX_AGGS 8
-struct DevAggSet {
-	DevAgg a[POLR_MAX_AGGS];
-	uint32_t n;
-	uint32_t pad;
-};
-
 __device__ __forceinline__ long long agg_cell(const DevCol &c, uint32_t row) {
 	const uint8_t *p = c.data + (uint64_t)row * c.width;
 	const bool sx = (c.flags & 1u) != 0;
@@ -246,20 +233,6 @@ struct GroupCell {
 	long long hi32;          // sum of (v >> 32), arithmetic
 	long long mn, mx;
 	unsigned long long count;
-};
-
-struct DevGroupKey {
-	DevCol src;
-	uint32_t slot;
-	uint32_t n_values;
-	int64_t min_value;
-};
-
-#define POLR_MAX_GROUP_KEYS 3
-struct DevGroupSet {
-	DevGroupKey k[POLR_MAX_GROUP_KEYS];
-	uint32_t n;
-	uint32_t n_groups;
 };
 
 #define POLR_GROUP_LDS_CELLS 1024
@@ -521,6 +494,180 @@ extern "C" int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_
 	return POLR_OK;
 }
 
+
+// ---- the GROUP BY sink fused into an emitting flat pipeline (FusedSink, polr_device.h; polr_flat_device.h) -------------
+static_assert(POLR_AGG_COUNT_STAR == POLR_DEV_AGG_COUNT_STAR && POLR_AGG_COUNT == POLR_DEV_AGG_COUNT &&
+                  POLR_AGG_SUM == POLR_DEV_AGG_SUM,
+              "aggregate function codes");
+#define POLR_FUSED_TABLES 256u // one table of group cells per workgroup (modulo): the adds of a workgroup stay among themselves
+
+// sums the workgroup tables: out[w] += sum over the tables t = blockIdx.y, blockIdx.y + gridDim.y, ... of cells[t][w]
+// (out zeroed by the caller; the table loop is split over gridDim.y for loads in flight)
+__global__ __launch_bounds__(256) void polr_fused_reduce_kernel(const unsigned long long *__restrict__ cells, uint32_t n_tables,
+                                                                uint32_t words, unsigned long long *__restrict__ out) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= words) {
+		return;
+	}
+	unsigned long long s = 0;
+	for (uint32_t t = blockIdx.y; t < n_tables; t += gridDim.y) {
+		s += cells[(size_t)t * words + w];
+	}
+	if (s) {
+		atomicAdd(&out[w], s);
+	}
+}
+
+extern "C" int polr_out_fuse_grouped(polr_out *o, const polr_group_key *keys, uint32_t n_keys, const polr_agg_spec *specs,
+                                     uint32_t n_aggs) {
+	if (!o) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = o->pipe;
+	polr_ctx *ctx = p->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (!keys || n_keys == 0) { // un-fuse: the output object collects row ids again
+		if (o->fused_dev) {
+			HIPCHK(ctx, hipDeviceSynchronize());
+			hipFree(o->fused_dev);
+			hipFree(o->fused_cells);
+			hipFree(o->fused_dropped);
+			o->fused_dev = nullptr;
+			o->fused_cells = o->fused_dropped = nullptr;
+			o->dev.fused = nullptr;
+		}
+		return POLR_OK;
+	}
+	if (!specs || n_aggs == 0 || n_keys > POLR_MAX_GROUP_KEYS || n_aggs > POLR_MAX_AGGS) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "1..%d group columns and 1..%d aggregates", POLR_MAX_GROUP_KEYS, POLR_MAX_AGGS);
+	}
+	if (!p->host_count.flat || !p->flat_emit) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED,
+		          "a GROUP BY sink is fused into FLAT pipelines whose joins are all perfect tables (polr_pipeline_launch_info); "
+		          "others: polr_out_aggregate_grouped over the emitted row ids");
+	}
+	if (o->fused_dev) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "the output object already has a fused sink");
+	}
+	FusedSink fs;
+	memset(&fs, 0, sizeof(fs));
+	fs.groups.n = n_keys;
+	uint64_t groups = 1;
+	for (uint32_t q = 0; q < n_keys; q++) {
+		const OwnedCol *c = nullptr;
+		uint32_t slot = 0;
+		int rc = resolve_agg_col(p, keys[q].src_join, keys[q].src_col, &c, &slot, "group column", q);
+		if (rc) {
+			return rc;
+		}
+		groups *= keys[q].n_values;
+		if (keys[q].n_values == 0 || groups > 4096) {
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "group column %u: a fused sink holds at most 4096 groups", q);
+		}
+		fs.groups.k[q].src.data = c->data;
+		fs.groups.k[q].src.valid = c->valid;
+		fs.groups.k[q].src.width = c->width;
+		fs.groups.k[q].src.flags = c->flags;
+		fs.groups.k[q].slot = slot;
+		fs.groups.k[q].n_values = keys[q].n_values;
+		fs.groups.k[q].min_value = keys[q].min_value;
+	}
+	fs.groups.n_groups = (uint32_t)groups;
+	fs.aggs.n = n_aggs;
+	for (uint32_t a = 0; a < n_aggs; a++) {
+		if (specs[a].fn > POLR_AGG_SUM) {
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "aggregate %u: a fused sink computes COUNT(*), COUNT and SUM", a);
+		}
+		fs.aggs.a[a].fn = specs[a].fn;
+		o->fused_fn[a] = specs[a].fn;
+		o->fused_has_valid[a] = false;
+		if (specs[a].fn == POLR_AGG_COUNT_STAR) {
+			continue;
+		}
+		const OwnedCol *c = nullptr;
+		uint32_t slot = 0;
+		int rc = resolve_agg_col(p, specs[a].src_join, specs[a].src_col, &c, &slot, "aggregate", a);
+		if (rc) {
+			return rc;
+		}
+		if (specs[a].fn == POLR_AGG_SUM && c->width > 4) {
+			// (the cells hold plain 64-bit sums: exact for 2^32 rows of values below 2^31)
+			POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "aggregate %u: a fused SUM takes columns of at most 4 bytes", a);
+		}
+		fs.aggs.a[a].src.data = c->data;
+		fs.aggs.a[a].src.valid = c->valid;
+		fs.aggs.a[a].src.width = c->width;
+		fs.aggs.a[a].src.flags = c->flags;
+		fs.aggs.a[a].slot = slot;
+		o->fused_has_valid[a] = c->valid != nullptr;
+	}
+	const uint32_t words = (uint32_t)groups * (1u + 2u * n_aggs);
+	fs.n_tables = POLR_FUSED_TABLES;
+	fs.words_per_table = words;
+	const size_t bytes = (size_t)(POLR_FUSED_TABLES + 1u) * words * 8u; // (+ 1: where the read-out sums the tables)
+	HIPCHK(ctx, hipMalloc((void **)&o->fused_cells, bytes));
+	HIPCHK(ctx, hipMalloc((void **)&o->fused_dropped, 8));
+	HIPCHK(ctx, hipMalloc((void **)&o->fused_dev, sizeof(FusedSink)));
+	fs.cells = o->fused_cells;
+	fs.dropped = o->fused_dropped;
+	HIPCHK(ctx, hipMemsetAsync(o->fused_cells, 0, bytes, ctx->stream));
+	HIPCHK(ctx, hipMemsetAsync(o->fused_dropped, 0, 8, ctx->stream));
+	HIPCHK(ctx, hipMemcpyAsync(o->fused_dev, &fs, sizeof(fs), hipMemcpyHostToDevice, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	o->fused_tables = POLR_FUSED_TABLES;
+	o->fused_groups = (uint32_t)groups;
+	o->fused_aggs = n_aggs;
+	o->dev.fused = o->fused_dev;
+	return POLR_OK;
+}
+
+extern "C" int polr_out_fused_result(polr_out *o, void *stream, polr_agg_value *results, uint64_t n_groups, uint64_t *n_dropped) {
+	if (!o || !results) {
+		return POLR_E_INVALID;
+	}
+	polr_ctx *ctx = o->pipe->ctx;
+	if (!o->fused_dev) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "the output object has no fused sink (polr_out_fuse_grouped)");
+	}
+	if (n_groups != o->fused_groups) {
+		POLR_FAIL(ctx, POLR_E_INVALID, "results hold %llu groups, the sink %u", (unsigned long long)n_groups, o->fused_groups);
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	const uint32_t n_aggs = o->fused_aggs, words = o->fused_groups * (1u + 2u * n_aggs);
+	unsigned long long *sum = o->fused_cells + (size_t)o->fused_tables * words; // (one more table behind the workgroups')
+	HIPCHK(ctx, hipMemsetAsync(sum, 0, (size_t)words * 8u, st));
+	hipLaunchKernelGGL(polr_fused_reduce_kernel, dim3((words + 255) / 256, 16), dim3(256), 0, st, o->fused_cells, o->fused_tables,
+	                   words, sum);
+	std::vector<unsigned long long> host(words);
+	unsigned long long dropped = 0;
+	hipError_t e = hipMemcpyAsync(host.data(), sum, (size_t)words * 8u, hipMemcpyDeviceToHost, st);
+	e = e == hipSuccess ? hipMemcpyAsync(&dropped, o->fused_dropped, 8, hipMemcpyDeviceToHost, st) : e;
+	e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "fused aggregate read-out failed: %s", hipGetErrorString(e));
+	}
+	for (uint32_t g = 0; g < o->fused_groups; g++) {
+		const unsigned long long *c = &host[(size_t)g * (1u + 2u * n_aggs)];
+		for (uint32_t a = 0; a < n_aggs; a++) {
+			polr_agg_value &v = results[(size_t)g * n_aggs + a];
+			memset(&v, 0, sizeof(v));
+			const uint64_t count = o->fused_fn[a] == POLR_AGG_COUNT_STAR || !o->fused_has_valid[a] ? c[0] : c[2u + 2u * a];
+			v.count = count;
+			if (o->fused_fn[a] == POLR_AGG_SUM) {
+				v.is_null = count == 0;
+				v.lo = (int64_t)c[1u + 2u * a];
+				v.hi = v.lo < 0 ? -1 : 0;
+			} else {
+				v.lo = (int64_t)count;
+			}
+		}
+	}
+	if (n_dropped) {
+		*n_dropped = dropped;
+	}
+	return POLR_OK;
+}
 
 // ---- VARCHAR: string heaps on the device and the MIN / MAX sink over string_t cells -------------------------------------
 // (string_type.hpp:23-28: {u32 length, char inlined[12]} or {u32 length, char prefix[4], char *ptr})

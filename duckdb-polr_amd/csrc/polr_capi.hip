@@ -1732,6 +1732,11 @@ int polr_out_reset(polr_out *o, void *stream) {
 	hipStream_t st = polr_stream(ctx, stream);
 	HIPCHK(ctx, hipMemsetAsync(o->dev.chunk_count, 0, (uint64_t)o->dev.max_chunks * 4, st));
 	HIPCHK(ctx, hipMemsetAsync(o->dev.cursor, 0, 8, st));
+	if (o->fused_cells) { // (a fused GROUP BY sink: its cells start from zero, too)
+		HIPCHK(ctx, hipMemsetAsync(o->fused_cells, 0,
+		                           (size_t)o->fused_tables * o->fused_groups * (1u + 2u * o->fused_aggs) * 8u, st));
+		HIPCHK(ctx, hipMemsetAsync(o->fused_dropped, 0, 8, st));
+	}
 	o->stats_valid = false;
 	return POLR_OK;
 }
@@ -1901,6 +1906,15 @@ void polr_out_destroy(polr_out *o) {
 	}
 	if (o->total_dev) {
 		hipFree(o->total_dev);
+	}
+	if (o->fused_dev) {
+		hipFree(o->fused_dev);
+	}
+	if (o->fused_cells) {
+		hipFree(o->fused_cells);
+	}
+	if (o->fused_dropped) {
+		hipFree(o->fused_dropped);
 	}
 	polr_ctx *ctx_ = o->ctx;
 	delete o;

@@ -223,6 +223,7 @@ struct DevRound {
 };
 
 // chunked output (a DataChunk stream of row ids)
+struct FusedSink;
 struct DevOut {
 	uint32_t *ids;          // [W_out][max_chunks * chunk_capacity]
 	uint32_t *chunk_count;  // [max_chunks]
@@ -232,6 +233,50 @@ struct DevOut {
 	uint32_t max_chunks;
 	uint32_t W_out;
 	uint32_t pad;
+	const FusedSink *fused; // nullptr: row ids are written (see FusedSink below)
+};
+
+// ---- aggregate sinks (polr_agg.hip; the flat pipeline's fused GROUP BY, polr_flat_device.h) ---------------------------
+struct DevAgg {
+	DevCol src;
+	uint32_t slot; // 0: probe row ids, 1 + j: build row ids of join j
+	uint32_t fn;
+};
+
+#define POLR_MAX_AGGS 8
+struct DevAggSet {
+	DevAgg a[POLR_MAX_AGGS];
+	uint32_t n;
+	uint32_t pad;
+};
+
+struct DevGroupKey {
+	DevCol src;
+	uint32_t slot;
+	uint32_t n_values;
+	int64_t min_value;
+};
+
+#define POLR_MAX_GROUP_KEYS 3
+struct DevGroupSet {
+	DevGroupKey k[POLR_MAX_GROUP_KEYS];
+	uint32_t n;
+	uint32_t n_groups;
+};
+
+// A perfect-hash GROUP BY of COUNT / SUM aggregates FUSED into the last join of an emitting flat pipeline
+// (polr_out_fuse_grouped): instead of writing its row ids, a surviving tuple is folded into the group cells of its
+// workgroup's table -- [n_tables][n_groups][1 + 2 n_aggs] 64-bit words (rows of the group; per aggregate sum, count) in
+// global memory, updated with atomics nobody waits for; the tables are summed when the result is read.
+#define POLR_DEV_AGG_COUNT_STAR 0u // (= POLR_AGG_COUNT_STAR / _COUNT / _SUM of polr_hip.h: static_assert in polr_agg.hip)
+#define POLR_DEV_AGG_COUNT 1u
+#define POLR_DEV_AGG_SUM 2u
+struct FusedSink {
+	DevGroupSet groups;
+	DevAggSet aggs;
+	unsigned long long *cells;
+	unsigned long long *dropped;
+	uint32_t n_tables, words_per_table;
 };
 
 __host__ __device__ inline uint64_t polr_murmurhash64(uint64_t x) {

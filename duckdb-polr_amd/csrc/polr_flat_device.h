@@ -98,6 +98,7 @@ struct FlatCtx {
 	DevOut out;
 	bool emit, overflow;
 	uint32_t cur_chunk, fill;
+	POLR_LDS unsigned long long *fused_lds; // the workgroup's group cells of a fused GROUP BY sink, when they fit in LDS
 	// stage 0's next step, requested one step ahead (the key stream's HBM round trip overlaps the current step)
 	uint4 pf0, pf1;
 	uint64_t pf_pos; // source position the prefetched keys belong to; ~0: none
@@ -215,6 +216,90 @@ __device__ __forceinline__ void flat_lookup(const FlatStage &s, const POLR_LDS u
                          // inlined at every place a stage emits it cost the SF100 headline 6 % -- 96 more spilled SGPRs)
 #endif
 #define FLAT_NO_CHUNK 0xFFFFFFFFu
+// one cell of a column of the aggregate sinks, as a signed 64-bit value (narrow unsigned values zero-extended)
+__device__ __forceinline__ long long flat_sink_cell(const DevCol &c, uint32_t row) {
+	const POLR_GLOBAL uint8_t *p = as_global(c.data) + (uint64_t)row * c.width;
+	const bool sx = (c.flags & 1u) != 0;
+	switch (c.width) {
+	case 1:
+		return sx ? (long long)*(const POLR_GLOBAL int8_t *)p : (long long)*p;
+	case 2:
+		return sx ? (long long)*(const POLR_GLOBAL int16_t *)p : (long long)*(const POLR_GLOBAL uint16_t *)p;
+	case 4:
+		return sx ? (long long)*(const POLR_GLOBAL int32_t *)p : (long long)*(const POLR_GLOBAL uint32_t *)p;
+	default:
+		return *(const POLR_GLOBAL long long *)p;
+	}
+}
+
+// the fused GROUP BY sink (FusedSink, polr_device.h): slot 0 = the probe row, slot 1 + j = the build id of join j, which
+// the stage that probed join j holds (id[p], out_slot = 1 + j).  One lane = one surviving tuple.
+template <int K>
+__device__ __forceinline__ void flat_fused_accumulate(FlatCtx<K> &c, uint32_t row) {
+	const FusedSink *f = c.out.fused; // (a generic pointer: the descriptor is read a few times per surviving tuple)
+	auto slot_row = [&](uint32_t slot) { // (slot is wave-uniform: one stage's key column is read, if any)
+		uint32_t r = row;
+#pragma unroll
+		for (int p = 0; p < K; p++) {
+			if (p < (int)c.k && c.st[p].out_slot == slot) {
+				r = c.st[p].keys[row] - c.st[p].a;
+			}
+		}
+		return r;
+	};
+	uint64_t g = 0;
+	bool ok = true;
+	for (uint32_t q = 0; q < f->groups.n; q++) {
+		const DevGroupKey gk = f->groups.k[q];
+		const uint32_t r = slot_row(gk.slot);
+		if (gk.src.valid && !as_global(gk.src.valid)[r]) {
+			ok = false;
+			break;
+		}
+		const unsigned long long off = (unsigned long long)(flat_sink_cell(gk.src, r) - gk.min_value);
+		if (off >= gk.n_values) {
+			ok = false;
+			break;
+		}
+		g = g * gk.n_values + off;
+	}
+	if (!ok) {
+		__hip_atomic_fetch_add(f->dropped, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return;
+	}
+	const uint32_t n_aggs = f->aggs.n;
+	// the cells of this workgroup: in LDS when they fit (flushed when the workgroup leaves: 25 M adds to a few hundred
+	// global addresses cost the SF100 run 1.9 ms), else its table in global memory; adds nobody waits for either way
+	const size_t at = g * (1u + 2u * n_aggs);
+	unsigned long long *gcell = f->cells + (size_t)(blockIdx.x % f->n_tables) * f->words_per_table + at;
+	POLR_LDS unsigned long long *lcell = c.fused_lds + at;
+	const bool in_lds = c.fused_lds != nullptr;
+	auto add = [&](uint32_t w, unsigned long long v) {
+		if (in_lds) {
+			__hip_atomic_fetch_add(&lcell[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		} else {
+			__hip_atomic_fetch_add(&gcell[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	};
+	add(0, 1ull);
+	for (uint32_t a = 0; a < n_aggs; a++) {
+		const DevAgg ag = f->aggs.a[a];
+		if (ag.fn == POLR_DEV_AGG_COUNT_STAR) {
+			continue; // (= the rows of the group)
+		}
+		const uint32_t r = slot_row(ag.slot);
+		if (ag.src.valid) {
+			if (!as_global(ag.src.valid)[r]) {
+				continue;
+			}
+			add(2u + 2u * a, 1ull);
+		}
+		if (ag.fn == POLR_DEV_AGG_SUM) {
+			add(1u + 2u * a, (unsigned long long)flat_sink_cell(ag.src, r));
+		}
+	}
+}
+
 // the tuples that survived the last join leave as row ids (emitting runs): the probe row, and for every join the build id
 // its key stands for -- every join of an emitting flat pipeline is a perfect table, whose build id IS key - min
 // (RowOperations::Gather reads payload columns re-ordered that way: polr_gather.hip) -- re-read from the probe columns
@@ -233,6 +318,16 @@ __device__ __forceinline__ void flat_out_write(FlatCtx<K> &c, uint32_t pos, bool
 	if (valid) {
 		const uint64_t tp = c.unit_begin + pos;
 		row = c.sel ? c.sel[tp] : (uint32_t)tp;
+	}
+	if (c.out.fused) {
+		// a fused GROUP BY sink: the tuple is folded into the group cells of its workgroup, nothing is written (and only
+		// the build ids the sink's columns hang on are re-read)
+		if (valid) {
+			flat_fused_accumulate<K>(c, row);
+		}
+		return;
+	}
+	if (valid) {
 #pragma unroll
 		for (int p = 0; p < K; p++) {
 			id[p] = p < (int)c.k ? c.st[p].keys[row] - c.st[p].a : 0u;
@@ -285,9 +380,18 @@ __device__ __forceinline__ void flat_emit(FlatCtx<K> &c, const uint32_t (&pos)[F
 	uint32_t total = 0;
 #if POLR_FLAT_EMIT
 	if (last && c.emit) {
-#pragma unroll
+		// (ONE copy of the sink's code per place a stage emits, not F: the loop stays a loop -- the element is picked
+		// with selects -- or the emitting build is 2.4 ms where the counting build is 1.5)
+#pragma unroll 1
 		for (int i = 0; i < F; i++) {
-			flat_out_write<K>(c, pos[i], hit[i]);
+			uint32_t p_i = pos[0];
+			bool h_i = hit[0];
+#pragma unroll
+			for (int j = 1; j < F; j++) {
+				p_i = j == i ? pos[j] : p_i;
+				h_i = j == i ? hit[j] : h_i;
+			}
+			flat_out_write<K>(c, p_i, h_i);
 		}
 	}
 #endif

@@ -139,10 +139,12 @@ hipError_t polr_launch_poolg_kernelx(uint32_t W, uint32_t k, uint32_t n_blocks, 
 	int polr_pool_flat_occupancy_e_k##KK(uint32_t waves_per_block, uint32_t table_dwords);                            \
 	hipError_t polr_launch_pool_flat_kernel_k##KK(uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords, \
 	                                              hipStream_t stream, const DevPipeline *pipe,                        \
-	                                              const ResidentExec *execs, PoolRun *run, DevOut out);               \
+	                                              const ResidentExec *execs, PoolRun *run, DevOut out,                \
+	                                              uint32_t fused_words);                                              \
 	hipError_t polr_launch_pool_flat_kernel_e_k##KK(uint32_t n_blocks, uint32_t waves_per_block,                      \
 	                                                uint32_t table_dwords, hipStream_t stream, const DevPipeline *pipe, \
-	                                                const ResidentExec *execs, PoolRun *run, DevOut out);
+	                                                const ResidentExec *execs, PoolRun *run, DevOut out,              \
+	                                                uint32_t fused_words);
 DECL_POOL_K(2)
 DECL_POOL_K(4)
 DECL_POOL_K(6)
@@ -254,15 +256,15 @@ extern "C++" int polr_pool_flat_occupancy(uint32_t k, uint32_t wpb, uint32_t tab
 // emit: the run may write row ids (the build of the flat kernel that carries that code)
 extern "C++" hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t wpb, uint32_t table_dwords,
                                                      hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                                     PoolRun *run, DevOut out, bool emit) {
+                                                     PoolRun *run, DevOut out, bool emit, uint32_t fused_words) {
 	if (emit) {
-		POOL_SWITCH(k, polr_launch_pool_flat_kernel_e_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
-		            polr_launch_pool_flat_kernel_e_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
-		            polr_launch_pool_flat_kernel_e_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
-		            polr_launch_pool_flat_kernel_e_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out))
+		POOL_SWITCH(k, polr_launch_pool_flat_kernel_e_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, fused_words),
+		            polr_launch_pool_flat_kernel_e_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, fused_words),
+		            polr_launch_pool_flat_kernel_e_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, fused_words),
+		            polr_launch_pool_flat_kernel_e_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, fused_words))
 	}
-	POOL_SWITCH(k, polr_launch_pool_flat_kernel_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
-	            polr_launch_pool_flat_kernel_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
-	            polr_launch_pool_flat_kernel_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out),
-	            polr_launch_pool_flat_kernel_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out))
+	POOL_SWITCH(k, polr_launch_pool_flat_kernel_k2(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, 0u),
+	            polr_launch_pool_flat_kernel_k4(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, 0u),
+	            polr_launch_pool_flat_kernel_k6(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, 0u),
+	            polr_launch_pool_flat_kernel_k8(n_blocks, wpb, table_dwords, stream, pipe, execs, run, out, 0u))
 }

@@ -134,6 +134,12 @@ struct polr_out {
 	uint64_t n_rows = 0;
 	uint32_t n_chunks = 0;
 	bool stats_valid = false;
+	// a fused GROUP BY sink (polr_out_fuse_grouped): the device descriptor, its cell tables, and what the result needs
+	FusedSink *fused_dev = nullptr;
+	unsigned long long *fused_cells = nullptr, *fused_dropped = nullptr;
+	uint32_t fused_tables = 0, fused_groups = 0, fused_aggs = 0;
+	uint32_t fused_fn[8] = {};
+	bool fused_has_valid[8] = {};
 };
 
 #define POLR_FAIL(ctx_, code_, ...)                                                                                    \
@@ -181,7 +187,7 @@ size_t polr_pool_flat_wave_bytes(uint32_t k);
 int polr_pool_flat_occupancy(uint32_t k, uint32_t waves_per_block, uint32_t table_dwords, bool emit);
 hipError_t polr_launch_pool_flat_kernel(uint32_t k, uint32_t n_blocks, uint32_t waves_per_block, uint32_t table_dwords,
                                         hipStream_t stream, const DevPipeline *pipe, const ResidentExec *execs,
-                                        PoolRun *run, DevOut out, bool emit);
+                                        PoolRun *run, DevOut out, bool emit, uint32_t fused_words);
 void polr_launch_gather(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks, uint32_t slot,
                         DevCol src, uint8_t *dst_data, uint8_t *dst_valid);
 void polr_launch_compact_ids(hipStream_t stream, DevOut out, const uint64_t *chunk_base, uint32_t n_chunks,

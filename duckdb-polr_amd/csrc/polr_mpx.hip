@@ -828,9 +828,18 @@ static int run_resident_impl(polr_mpx **ms, void *stream, const uint64_t *chunk_
 		HIPCHK(ctx, hipEventRecord(m0->ev_start[ev], st));
 	}
 	const ResidentExec *execs_dev = (const ResidentExec *)(m0->execs_dev + POOL_HEADER_BYTES);
+	// a fused GROUP BY sink keeps its cells in the workgroup's LDS when they fit behind the bit tables and the queues
+	// (160 KB per workgroup), else in its table in global memory
+	uint32_t fused_words = 0;
+	if (flat && out && out->fused_dev) {
+		const uint64_t words = (uint64_t)out->fused_groups * (1u + 2u * out->fused_aggs);
+		if (polr_pool_flat_lds_bytes(dp.k, wpb, dp.lds_table_dwords) + 8 + words * 8 <= 160u * 1024u) {
+			fused_words = (uint32_t)words;
+		}
+	}
 	hipError_t e =
 	    flat ? polr_launch_pool_flat_kernel(dp.k, n_blocks, wpb, dp.lds_table_dwords, st, p->dev_count, execs_dev,
-	                                        (PoolRun *)m0->execs_dev, dout, materialize)
+	                                        (PoolRun *)m0->execs_dev, dout, materialize, fused_words)
 	         : polr_launch_pool_kernel(wq, dp.k, n_blocks, st, materialize ? p->dev_mat : p->dev_count, execs_dev,
 	                                   (PoolRun *)m0->execs_dev, dout, dp.ext != 0);
 	if (e != hipSuccess) {

@@ -37,7 +37,7 @@ template <int K, int EMIT>
 __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline *__restrict__ pipe,
                                                               const ResidentExec *__restrict__ execs, PoolRun *run,
                                                               DevOut out, uint32_t lds_per_wave, uint32_t table_dwords,
-                                                              uint32_t router_dwords) {
+                                                              uint32_t router_dwords, uint32_t fused_off, uint32_t fused_words) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const uint32_t wave_in_block = threadIdx.x >> 6;
 	const uint32_t k = uni(pipe->k);
@@ -47,6 +47,13 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 		pool_router_wave(execs, run, rh, k, FLAT_STEP0, lds, router_dwords);
 		return;
 	}
+#if POLR_FLAT_EMIT
+	// a fused GROUP BY sink whose cells fit: this workgroup's cells start from zero (published by the barrier below)
+	POLR_LDS unsigned long long *fused_lds = fused_words ? as_lds((unsigned long long *)(lds + fused_off)) : nullptr;
+	for (uint32_t i = threadIdx.x; i < fused_words; i += blockDim.x) {
+		fused_lds[i] = 0ull;
+	}
+#endif
 	// the bit tables that fit stay in LDS for the whole run: one cooperative copy per workgroup
 	{
 		const uint32_t n_tab = uni(pipe->n_lds_tables);
@@ -84,6 +91,11 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 	c.overflow = false;
 	c.cur_chunk = FLAT_NO_CHUNK;
 	c.fill = 0;
+#if POLR_FLAT_EMIT
+	c.fused_lds = fused_lds;
+#else
+	c.fused_lds = nullptr;
+#endif
 	c.unit_begin = c.in_pos = c.in_end = 0;
 	c.pf_pos = ~0ull;
 	c.pf0 = make_uint4(0, 0, 0, 0);
@@ -139,6 +151,18 @@ __global__ __launch_bounds__(1024) void polr_pool_flat_kernel(const DevPipeline 
 #if POLR_FLAT_EMIT
 	if (c.cur_chunk != FLAT_NO_CHUNK && c.lane == 0) {
 		out.chunk_count[c.cur_chunk] = c.fill;
+	}
+	if (fused_words) {
+		// every wave of the workgroup has left its loop: flush the cells that were touched to the workgroup's table
+		__syncthreads();
+		const FusedSink *f = out.fused;
+		unsigned long long *table = f->cells + (size_t)(blockIdx.x % f->n_tables) * f->words_per_table;
+		for (uint32_t i = threadIdx.x; i < fused_words; i += blockDim.x) {
+			const unsigned long long v = fused_lds[i];
+			if (v) {
+				__hip_atomic_fetch_add(&table[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
 	}
 #endif
 }
@@ -203,9 +227,11 @@ extern "C++" int FLAT_EXPORT(polr_pool_flat_occupancy_)(uint32_t waves_per_block
 extern "C++" hipError_t FLAT_EXPORT(polr_launch_pool_flat_kernel_)(uint32_t n_blocks, uint32_t waves_per_block,
                                                                       uint32_t table_dwords, hipStream_t stream,
                                                                       const DevPipeline *pipe, const ResidentExec *execs,
-                                                                      PoolRun *run, DevOut out) {
+                                                                      PoolRun *run, DevOut out, uint32_t fused_words) {
+	// (fused_words: 64-bit group cells of a fused GROUP BY sink to keep in LDS behind everything else; 0: none)
 	const size_t dwords = pool_flat_lds_dwords(waves_per_block, table_dwords);
-	const size_t lds = dwords * sizeof(uint32_t);
+	const uint32_t fused_off = (uint32_t)((dwords + 1) & ~(size_t)1);
+	const size_t lds = (fused_words ? (size_t)fused_off + 2 * (size_t)fused_words : dwords) * sizeof(uint32_t);
 	hipError_t e = pool_flat_prepare(lds);
 	if (e != hipSuccess) {
 		return e;
@@ -213,7 +239,8 @@ extern "C++" hipError_t FLAT_EXPORT(polr_launch_pool_flat_kernel_)(uint32_t n_bl
 	uint32_t per_wave = (uint32_t)pool_flat_wave_dwords();
 	uint32_t router_dwords = (uint32_t)(dwords / waves_per_block);
 	dim3 grid(n_blocks), block(64 * waves_per_block);
-	void *args[] = {(void *)&pipe, (void *)&execs, (void *)&run, (void *)&out, (void *)&per_wave, (void *)&table_dwords,
-	                (void *)&router_dwords};
+	uint32_t fused_off_arg = fused_words ? fused_off : 0u;
+	void *args[] = {(void *)&pipe,         (void *)&execs,         (void *)&run,           (void *)&out,        (void *)&per_wave,
+	                (void *)&table_dwords, (void *)&router_dwords, (void *)&fused_off_arg, (void *)&fused_words};
 	return hipLaunchKernel((const void *)polr_pool_flat_kernel<POLR_K, POLR_FLAT_EMIT>, grid, block, args, lds, stream);
 }

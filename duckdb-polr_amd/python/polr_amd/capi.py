@@ -36,6 +36,7 @@ EXPORTS = [
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
     "polr_ctx_set_pool_tuning", "polr_ctx_get_stream",
     "polr_ht_set_payload_heap", "polr_pipeline_set_probe_heap", "polr_out_aggregate_string", "polr_ht_set_key_flags",
+    "polr_out_fuse_grouped", "polr_out_fused_result",
 ]
 
 
@@ -186,6 +187,8 @@ def load():
     L.polr_mpx_use_scan_chunks.argtypes = [vp]
     L.polr_out_aggregate.argtypes = [vp, vp, vp, u32, vp]
     L.polr_out_aggregate_grouped.argtypes = [vp, vp, vp, u32, vp, u32, vp, C.c_uint64, vp]
+    L.polr_out_fuse_grouped.argtypes = [vp, vp, u32, vp, u32]
+    L.polr_out_fused_result.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_run_resident_morsels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, u32, vp, u32]
     L.polr_mpx_run_backpressure.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, vp, u32]
@@ -568,6 +571,36 @@ class Output:
         dropped = C.c_uint64()
         self.ctx.check(self.ctx.L.polr_out_aggregate_grouped(self.h, stream, ka, nk, sa, na, res, n_groups,
                                                              C.byref(dropped)))
+        vals = [[None if res[g * na + a].is_null else (res[g * na + a].hi << 64) + (res[g * na + a].lo & 0xFFFFFFFFFFFFFFFF)
+                 for a in range(na)] for g in range(n_groups)]
+        counts = [[res[g * na + a].count for a in range(na)] for g in range(n_groups)]
+        return vals, counts, dropped.value
+
+    def fuse_grouped(self, keys, specs):
+        """polr_out_fuse_grouped: fold the join result into group cells inside the run (flat pipelines of perfect tables;
+        COUNT(*) / COUNT / SUM).  keys / specs as in aggregate_grouped; keys=None un-fuses.  reset() zeroes the cells."""
+        if keys is None:
+            self.ctx.check(self.ctx.L.polr_out_fuse_grouped(self.h, None, 0, None, 0))
+            self._fused = None
+            return
+        nk, na = len(keys), len(specs)
+        ka = (GroupKey * nk)()
+        n_groups = 1
+        for i, (sj, sc, mn, nv) in enumerate(keys):
+            ka[i].src_join, ka[i].src_col, ka[i].min_value, ka[i].n_values = sj, sc, int(mn), int(nv)
+            n_groups *= int(nv)
+        sa = (AggSpec * na)()
+        for i, (fn, sj, sc) in enumerate(specs):
+            sa[i].fn, sa[i].src_join, sa[i].src_col = AGG[fn] if isinstance(fn, str) else fn, sj, sc
+        self.ctx.check(self.ctx.L.polr_out_fuse_grouped(self.h, ka, nk, sa, na))
+        self._fused = (n_groups, na)
+
+    def fused_result(self, stream=None):
+        """polr_out_fused_result -> (values[n_groups][n_aggs], counts[n_groups][n_aggs], n_dropped), as aggregate_grouped"""
+        n_groups, na = self._fused
+        res = (AggValue * (n_groups * na))()
+        dropped = C.c_uint64()
+        self.ctx.check(self.ctx.L.polr_out_fused_result(self.h, stream, res, n_groups, C.byref(dropped)))
         vals = [[None if res[g * na + a].is_null else (res[g * na + a].hi << 64) + (res[g * na + a].lo & 0xFFFFFFFFFFFFFFFF)
                  for a in range(na)] for g in range(n_groups)]
         counts = [[res[g * na + a].count for a in range(na)] for g in range(n_groups)]

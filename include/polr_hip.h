@@ -354,6 +354,16 @@ typedef struct polr_group_key {
 int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_group_key *keys, uint32_t n_keys,
                                const polr_agg_spec *specs, uint32_t n_aggs, polr_agg_value *results,
                                uint64_t n_groups, uint64_t *n_dropped);
+/* The same GROUP BY FUSED into the run (SSB-skew Q4.1 as shipped: benchmark/ssb-skew/queries/q4-1.sql): an output object
+ * with a fused sink makes the pipeline's LAST join fold every surviving tuple into the group cells instead of writing its
+ * row ids -- nothing of the join result is written or read back.  For FLAT pipelines whose joins are all perfect tables
+ * (polr_pipeline_launch_info(p, 1): flat) -- the star joins of SSB; COUNT(*), COUNT and SUM over columns of at most 4
+ * bytes, at most 4096 groups; POLR_E_UNSUPPORTED otherwise (then: polr_out_aggregate_grouped over the emitted row ids).
+ * polr_out_reset zeroes the cells; every run with this `out` adds to them; polr_out_fused_result reads them (results as
+ * for polr_out_aggregate_grouped).  keys == NULL un-fuses. */
+int polr_out_fuse_grouped(polr_out *o, const polr_group_key *keys, uint32_t n_keys, const polr_agg_spec *specs,
+                          uint32_t n_aggs);
+int polr_out_fused_result(polr_out *o, void *stream, polr_agg_value *results, uint64_t n_groups, uint64_t *n_dropped);
 /* ---- VARCHAR columns and their sink (every JOB query ends in MIN of a VARCHAR: benchmark/imdb_plan_cost/queries/18a.sql:1-3) --------
  * A width-16 column holds string_t cells (src/include/duckdb/common/types/string_type.hpp:23-28: 4-byte length; up to 12
  * characters inline; longer: a 4-byte prefix and an 8-byte pointer into a string heap).  RowOperations::Gather copies such

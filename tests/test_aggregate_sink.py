@@ -348,6 +348,64 @@ def test_device_q41_as_shipped_on_the_flat_pipeline(gpu_ctx, n_exec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_exec", [1, 16])
+def test_device_q41_as_shipped_with_the_sink_fused_into_the_run(gpu_ctx, n_exec):
+    """the same query with the GROUP BY FUSED into the flat pipeline's last join (polr_out_fuse_grouped): no row id is
+    written, the group cells are the only output.  Against the reference's answer and against the two-kernel path; passes
+    add up until the output object is reset; what a fused sink cannot do is refused"""
+    from polr_amd import capi, ssb_skew
+    gold, want = _q41_shipped_want()
+    wl = ssb_skew.workload("q4.1", **gold["shape"])
+    inst = wl["instance"]
+    m = inst.lineorder(0, inst.n_lo, cols=["lo_revenue", "lo_supplycost"])
+    names = list(wl["probe"]["cols"].keys()) + ["lo_revenue", "lo_supplycost"]
+    cols = list(wl["probe"]["cols"].values()) + [m["lo_revenue"], m["lo_supplycost"]]
+    n = len(cols[0])
+    paths = np.asarray(common.load_golden("ssb_skew_sample")["cases"]["q4.1/3"]["paths"], dtype=np.int32)
+    joins = capi.build_joins(gpu_ctx, wl, auto=True)
+    pipe = capi.Pipeline(gpu_ctx, cols, n, joins, paths)
+    years = sorted({y for y, _c in want})
+    y0, ny = years[0], years[-1] - years[0] + 1
+    keys = [(3, 0, y0, ny), (0, 0, 0, 50)]
+    specs = [("count_star", -1, 0), ("sum", -1, names.index("lo_revenue")), ("sum", -1, names.index("lo_supplycost"))]
+    out = capi.Output(pipe, 1024, 64)  # (no room for the row ids: none are written)
+    out.fuse_grouped(keys, specs)
+    n_chunks = (n + 1023) // 1024
+    mpxs = [capi.DeviceMultiplexer(pipe, "adaptive_reinit") for _ in range(n_exec)]
+    ranges = [((e * n_chunks) // n_exec, ((e + 1) * n_chunks) // n_exec) for e in range(n_exec)]
+    for passes in (1, 2):
+        capi.run_resident(mpxs, ranges, out=out, reset=True, finish=True)
+        stats = capi.finish_many(mpxs)
+        vals, counts, dropped = out.fused_result()
+        assert dropped == 0
+        k = len(wl["joins"])
+        n_out = sum(sum(st["stage_out"][p][k - 1] for p in range(len(paths))) for st in stats)
+        seen = 0
+        for g_, v in enumerate(vals):
+            key = (y0 + g_ // 50, g_ % 50)
+            if key in want:
+                assert v[1] - v[2] == passes * want[key], key
+                seen += 1
+            else:
+                assert v[0] == 0 and v[1] is None
+        assert seen == len(want) and sum(v[0] for v in vals) == passes * n_out
+        assert out.stats()[0] == 0  # nothing was emitted
+    out.reset()
+    assert sum(v[0] for v in out.fused_result()[0]) == 0
+    # MIN / MAX and 8-byte SUMs stay with the two-kernel path; a second sink on the same object is refused
+    out2 = capi.Output(pipe, 1024, 64)
+    with pytest.raises(capi.PolrError) as e:
+        out2.fuse_grouped(keys, [("min", -1, names.index("lo_revenue"))])
+    assert e.value.code == capi.E_UNSUPPORTED
+    with pytest.raises(capi.PolrError):
+        out.fuse_grouped(keys, specs)
+    out.fuse_grouped(None, None)
+    for m_ in mpxs:
+        m_.close()
+    pipe.close()
+
+
+@pytest.mark.gpu
 def test_string_min_max_over_inline_and_heap_cells(gpu_ctx):
     """polr_out_aggregate_string over string_t cells: strings of 0 .. 40 bytes (inline up to 12, heap beyond), many sharing
     their first 4 / 12 / 20 bytes, bytes above 0x7F (compared unsigned), proper prefixes (the shorter first), NULL cells (take
