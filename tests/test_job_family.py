@@ -259,3 +259,50 @@ def test_pool_launch_and_path_kernel_agree_on_all_113(gpu_ctx):
         for ht, _ in joins:
             ht.close()
     assert checked == 113
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("share_after", [16, 0xFFFFFFFF])
+def test_heavy_fanout_shapes_with_work_sharing(gpu_ctx, share_after):
+    """the JOB shapes whose fan-out joins multiply (25c: one cast_info row meets hundreds of thousands of build-row triples
+    at scale 1; 17e, 31a, 19c) at scale 0.05, COUNTING runs -- multiplicities folded where nobody reads the build rows,
+    expansions where they are read -- with work sharing after 16 steps and with sharing off: the ADAPTIVE_REINIT trace, the
+    totals and COUNT(*) are the oracle's, whatever was cut and handed to other waves"""
+    from polr_amd import capi
+    t = _tables(0.05)
+    for name in ("25c", "17e", "31a", "19c"):
+        wl = jf.workload(name, t, SHAPES[name])
+        pn = list(wl["probe"]["cols"].keys())
+        paths = _each_last_once(wl)
+        oj = [orc.JoinSpec(orc.HashTable(j["keys"], list(j["payload"].values())), j["key_src"]) for j in wl["joins"]]
+        sel = wl["probe"].get("filter_sel")
+        offs = None
+        if sel is not None:
+            bounds = np.searchsorted(sel, np.arange(0, len(wl["probe"]["cols"][pn[0]]) + 1024, 1024, dtype=np.int64)).astype(np.uint64)
+            offs = bounds[np.concatenate([[True], bounds[1:] != bounds[:-1]])]
+        ref = orc.run_pipeline(list(wl["probe"]["cols"].values()), oj, paths, routing="adaptive_reinit", caching=False,
+                               collect_output=False, sel=sel, chunk_offsets=offs)
+        joins = capi.build_joins(gpu_ctx, wl, auto=True)
+        cols = list(wl["probe"]["cols"].values())
+        pipe = capi.Pipeline(gpu_ctx, cols, len(cols[0]), joins, paths)
+        flt = wl["probe"].get("filter")
+        if flt:
+            _n, n_chunks = pipe.scan_filter([(pn.index(c), op, const) for c, op, const in flt])
+        else:
+            n_chunks = (len(cols[0]) + 1023) // 1024
+        try:
+            gpu_ctx.set_pool_tuning(share_after=share_after)
+            mpx = capi.DeviceMultiplexer(pipe, "adaptive_reinit", max_log_rounds=1 << 16)
+            if flt:
+                mpx.use_scan_chunks()
+            capi.run_resident([mpx], [(0, n_chunks)], reset=True, finish=True)
+            st = mpx.finish()
+            _, _, inter = mpx.fetch_log()
+        finally:
+            gpu_ctx.set_pool_tuning()
+        k = len(wl["joins"])
+        assert list(inter) == list(ref["intermediates_per_round"]), name
+        assert st["num_intermediates"] == ref["num_intermediates"], name
+        assert sum(st["stage_out"][p][k - 1] for p in range(len(paths))) == ref["num_output_rows"], name
+        mpx.close()
+        pipe.close()
