@@ -605,15 +605,23 @@ extern "C" int polr_out_fuse_grouped(polr_out *o, const polr_group_key *keys, ui
 	fs.n_tables = POLR_FUSED_TABLES;
 	fs.words_per_table = words;
 	const size_t bytes = (size_t)(POLR_FUSED_TABLES + 1u) * words * 8u; // (+ 1: where the read-out sums the tables)
-	HIPCHK(ctx, hipMalloc((void **)&o->fused_cells, bytes));
-	HIPCHK(ctx, hipMalloc((void **)&o->fused_dropped, 8));
-	HIPCHK(ctx, hipMalloc((void **)&o->fused_dev, sizeof(FusedSink)));
+	hipError_t e = hipMalloc((void **)&o->fused_cells, bytes);
+	e = e == hipSuccess ? hipMalloc((void **)&o->fused_dropped, 8) : e;
+	e = e == hipSuccess ? hipMalloc((void **)&o->fused_dev, sizeof(FusedSink)) : e;
 	fs.cells = o->fused_cells;
 	fs.dropped = o->fused_dropped;
-	HIPCHK(ctx, hipMemsetAsync(o->fused_cells, 0, bytes, ctx->stream));
-	HIPCHK(ctx, hipMemsetAsync(o->fused_dropped, 0, 8, ctx->stream));
-	HIPCHK(ctx, hipMemcpyAsync(o->fused_dev, &fs, sizeof(fs), hipMemcpyHostToDevice, ctx->stream));
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	e = e == hipSuccess ? hipMemsetAsync(o->fused_cells, 0, bytes, ctx->stream) : e;
+	e = e == hipSuccess ? hipMemsetAsync(o->fused_dropped, 0, 8, ctx->stream) : e;
+	e = e == hipSuccess ? hipMemcpyAsync(o->fused_dev, &fs, sizeof(fs), hipMemcpyHostToDevice, ctx->stream) : e;
+	e = e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+	if (e != hipSuccess) { // (nothing half-made stays behind)
+		hipFree(o->fused_cells);
+		hipFree(o->fused_dropped);
+		hipFree(o->fused_dev);
+		o->fused_cells = o->fused_dropped = nullptr;
+		o->fused_dev = nullptr;
+		POLR_FAIL(ctx, POLR_E_HIP, "fused sink: %s", hipGetErrorString(e));
+	}
 	o->fused_tables = POLR_FUSED_TABLES;
 	o->fused_groups = (uint32_t)groups;
 	o->fused_aggs = n_aggs;

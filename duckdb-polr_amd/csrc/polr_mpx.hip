@@ -290,7 +290,9 @@ int polr_mpx_set_chunk_offsets(polr_mpx *m, const uint64_t *offsets, uint64_t n_
 // (launches that each declared a share, POLR_RUN_SHARE, are the caller's to add up) -- and open the entry whose event the
 // caller records behind the launch.  Same-stream launches are ordered by the stream.
 static int order_pool_launch(polr_ctx *ctx, hipStream_t st, uint32_t share) {
+	// (the lists change only when every call below has succeeded)
 	std::vector<polr_ctx::PoolLaunch> keep;
+	std::vector<hipEvent_t> retired;
 	for (auto &f : ctx->pool_launches) {
 		bool retire = f.stream == st; // (superseded: this stream's next launch carries the newer event)
 		if (!retire && (share <= 1 || f.share <= 1)) {
@@ -298,20 +300,24 @@ static int order_pool_launch(polr_ctx *ctx, hipStream_t st, uint32_t share) {
 			retire = share <= 1; // (everything enqueued later waits for THIS launch, which waits for f)
 		}
 		if (retire) {
-			ctx->pool_events_free.push_back(f.done);
+			retired.push_back(f.done);
 		} else {
 			keep.push_back(f);
 		}
 	}
-	ctx->pool_launches.swap(keep);
-	hipEvent_t done;
-	if (!ctx->pool_events_free.empty()) {
+	hipEvent_t done = nullptr;
+	if (!retired.empty()) {
+		done = retired.back();
+		retired.pop_back();
+	} else if (!ctx->pool_events_free.empty()) {
 		done = ctx->pool_events_free.back();
 		ctx->pool_events_free.pop_back();
 	} else {
 		HIPCHK(ctx, hipEventCreateWithFlags(&done, hipEventDisableTiming));
 	}
-	ctx->pool_launches.push_back({st, done, share});
+	ctx->pool_events_free.insert(ctx->pool_events_free.end(), retired.begin(), retired.end());
+	keep.push_back({st, done, share});
+	ctx->pool_launches.swap(keep);
 	return POLR_OK;
 }
 
