@@ -495,6 +495,295 @@ extern "C" int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_
 }
 
 
+// ---- the general GROUP BY sink: group columns of any integer domain (PhysicalHashAggregate,
+// src/execution/operator/aggregate/physical_hash_aggregate.cpp -- the plan when the group columns' statistics do not allow
+// a perfect-hash aggregate) -----------------------------------------------------------------------------------------------
+// An open-addressing table of groups in global memory: state[s] = 0 empty / 1 being written / 2 ready, the group's key
+// values (NULL is a group value of its own, as GROUP BY has it: a bit per column) and its cells.  A row claims an empty
+// slot with a compare-and-swap and publishes its key; every other row of the group finds the key and adds to the cells.
+// A lane that meets a slot "being written" does not wait inside the iteration -- the writer may be a lane of its own wave,
+// which runs in lockstep -- it comes back to the slot in the next iteration of the loop all lanes share.
+struct HashAggTable {
+	uint32_t *state;
+	long long *keys;          // [capacity][n_cols]
+	uint32_t *nulls;          // [capacity]: bit c = group column c is NULL
+	GroupCell *cells;         // [capacity][n_aggs]
+	unsigned long long *n_groups, *overflow;
+	uint64_t mask;            // capacity - 1
+	uint64_t max_groups;
+};
+
+__global__ __launch_bounds__(256) void polr_hash_agg_init_kernel(HashAggTable t, uint32_t n_aggs) {
+	const uint64_t n = (t.mask + 1) * n_aggs;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		t.cells[i].lo32 = 0;
+		t.cells[i].hi32 = 0;
+		t.cells[i].mn = 0x7FFFFFFFFFFFFFFFll;
+		t.cells[i].mx = (long long)0x8000000000000000ull;
+		t.cells[i].count = 0;
+	}
+}
+
+__global__ __launch_bounds__(256) void polr_hash_agg_kernel(DevOut out, uint32_t n_chunks, DevGroupSet groups, DevAggSet aggs,
+                                                            HashAggTable t) {
+	for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+		const uint32_t n = out.chunk_count[chunk];
+		const uint64_t chunk_base = (uint64_t)chunk * out.chunk_capacity;
+		for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+			const uint32_t i = i0 + threadIdx.x;
+			const bool active = i < n;
+			long long key[POLR_MAX_GROUP_KEYS] = {0, 0, 0};
+			uint32_t null_mask = 0;
+			uint64_t h = 0x9E3779B97F4A7C15ull;
+			if (active) {
+				for (uint32_t q = 0; q < groups.n; q++) {
+					const DevGroupKey &gk = groups.k[q];
+					const uint32_t row = out.ids[(uint64_t)gk.slot * out.slot_stride + chunk_base + i];
+					if (gk.src.valid && !gk.src.valid[row]) {
+						null_mask |= 1u << q;
+					} else {
+						key[q] = agg_cell(gk.src, row);
+					}
+					h = polr_murmurhash64(h ^ (uint64_t)key[q]) + q;
+				}
+				h = polr_murmurhash64(h ^ null_mask);
+			}
+			uint64_t s = h & t.mask;
+			bool done = !active;
+			uint64_t probes = 0;
+			while (__syncthreads_or(!done)) { // (every lane of the workgroup takes part in every iteration)
+				if (!done) {
+					uint32_t st = __hip_atomic_load(&t.state[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+					if (st == 0u) {
+						if (atomicCAS(&t.state[s], 0u, 1u) == 0u) {
+							if (atomicAdd(t.n_groups, 1ull) >= t.max_groups) {
+								atomicExch(t.overflow, 1ull); // (more groups than the caller made room for)
+							}
+							for (uint32_t q = 0; q < groups.n; q++) {
+								t.keys[s * groups.n + q] = key[q];
+							}
+							t.nulls[s] = null_mask;
+							__hip_atomic_store(&t.state[s], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+							st = 2u;
+						}
+					}
+					if (st == 2u) {
+						bool same = t.nulls[s] == null_mask;
+						for (uint32_t q = 0; q < groups.n; q++) {
+							same = same && t.keys[s * groups.n + q] == key[q];
+						}
+						if (same) {
+							done = true;
+						} else {
+							s = (s + 1) & t.mask;
+							if (++probes > t.mask) { // (a full table: cannot happen with capacity >= 2 x max_groups before overflow)
+								atomicExch(t.overflow, 1ull);
+								done = true;
+								s = ~0ull;
+							}
+						}
+					}
+					// (st == 1: somebody is writing this slot's key: look again in the next iteration)
+				}
+			}
+			if (active && s != ~0ull) {
+				for (uint32_t a = 0; a < aggs.n; a++) {
+					const DevAgg &ag = aggs.a[a];
+					GroupCell *c = &t.cells[s * aggs.n + a];
+					if (ag.fn == POLR_AGG_COUNT_STAR) {
+						atomicAdd(&c->count, 1ull);
+						continue;
+					}
+					const uint32_t row = out.ids[(uint64_t)ag.slot * out.slot_stride + chunk_base + i];
+					if (ag.src.valid && !ag.src.valid[row]) {
+						continue;
+					}
+					cell_add(c, agg_cell(ag.src, row));
+				}
+			}
+		}
+	}
+}
+
+// the groups that exist, compacted: [idx] <- slot
+__global__ __launch_bounds__(256) void polr_hash_agg_compact_kernel(HashAggTable t, uint32_t n_cols, uint32_t n_aggs, long long *keys_out,
+                                                                    uint32_t *nulls_out, GroupCell *cells_out, unsigned long long *cursor,
+                                                                    uint64_t max_groups) {
+	for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= t.mask; s += (uint64_t)gridDim.x * blockDim.x) {
+		if (t.state[s] != 2u) {
+			continue;
+		}
+		const unsigned long long idx = atomicAdd(cursor, 1ull);
+		if (idx >= max_groups) {
+			continue;
+		}
+		for (uint32_t q = 0; q < n_cols; q++) {
+			keys_out[idx * n_cols + q] = t.keys[s * n_cols + q];
+		}
+		nulls_out[idx] = t.nulls[s];
+		for (uint32_t a = 0; a < n_aggs; a++) {
+			cells_out[idx * n_aggs + a] = t.cells[s * n_aggs + a];
+		}
+	}
+}
+
+static void cell_to_value(const GroupCell &c, uint32_t fn, polr_agg_value &v) {
+	memset(&v, 0, sizeof(v));
+	v.count = c.count;
+	const __int128 sum = ((__int128)c.hi32 << 32) + (__int128)c.lo32;
+	switch (fn) {
+	case POLR_AGG_COUNT_STAR:
+	case POLR_AGG_COUNT:
+		v.lo = (int64_t)c.count;
+		break;
+	case POLR_AGG_SUM:
+		v.is_null = c.count == 0;
+		v.lo = (int64_t)(unsigned long long)sum;
+		v.hi = (int64_t)(sum >> 64);
+		break;
+	case POLR_AGG_MIN:
+		v.is_null = c.count == 0;
+		v.lo = c.count ? c.mn : 0;
+		v.hi = (c.count && c.mn < 0) ? -1 : 0;
+		break;
+	default:
+		v.is_null = c.count == 0;
+		v.lo = c.count ? c.mx : 0;
+		v.hi = (c.count && c.mx < 0) ? -1 : 0;
+		break;
+	}
+}
+
+extern "C" int polr_out_aggregate_hashed(polr_out *o, void *stream, const polr_group_key *cols, uint32_t n_cols,
+                                         const polr_agg_spec *specs, uint32_t n_aggs, uint64_t max_groups, int64_t *group_keys,
+                                         uint32_t *group_nulls, polr_agg_value *results, uint64_t *n_groups) {
+	if (!o || !cols || !specs || !group_keys || !group_nulls || !results || !n_groups || n_cols == 0 || n_aggs == 0 ||
+	    max_groups == 0) {
+		return POLR_E_INVALID;
+	}
+	polr_pipeline *p = o->pipe;
+	polr_ctx *ctx = p->ctx;
+	if (n_cols > POLR_MAX_GROUP_KEYS || n_aggs > POLR_MAX_AGGS || max_groups > (1ull << 24)) {
+		POLR_FAIL(ctx, POLR_E_UNSUPPORTED, "at most %d group columns, %d aggregates and 2^24 groups", POLR_MAX_GROUP_KEYS,
+		          POLR_MAX_AGGS);
+	}
+	DevGroupSet gs;
+	memset(&gs, 0, sizeof(gs));
+	gs.n = n_cols;
+	for (uint32_t q = 0; q < n_cols; q++) {
+		const OwnedCol *c = nullptr;
+		uint32_t slot = 0;
+		int rc = resolve_agg_col(p, cols[q].src_join, cols[q].src_col, &c, &slot, "group column", q);
+		if (rc) {
+			return rc;
+		}
+		gs.k[q].src.data = c->data;
+		gs.k[q].src.valid = c->valid;
+		gs.k[q].src.width = c->width;
+		gs.k[q].src.flags = c->flags;
+		gs.k[q].slot = slot;
+	}
+	DevAggSet as;
+	memset(&as, 0, sizeof(as));
+	as.n = n_aggs;
+	for (uint32_t a = 0; a < n_aggs; a++) {
+		if (specs[a].fn > POLR_AGG_MAX) {
+			POLR_FAIL(ctx, POLR_E_INVALID, "aggregate %u: unknown function %u", a, specs[a].fn);
+		}
+		as.a[a].fn = specs[a].fn;
+		if (specs[a].fn == POLR_AGG_COUNT_STAR) {
+			continue;
+		}
+		const OwnedCol *c = nullptr;
+		uint32_t slot = 0;
+		int rc = resolve_agg_col(p, specs[a].src_join, specs[a].src_col, &c, &slot, "aggregate", a);
+		if (rc) {
+			return rc;
+		}
+		as.a[a].src.data = c->data;
+		as.a[a].src.valid = c->valid;
+		as.a[a].src.width = c->width;
+		as.a[a].src.flags = c->flags;
+		as.a[a].slot = slot;
+	}
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = polr_stream(ctx, stream);
+	if (!o->stats_valid) {
+		int rc = polr_out_stats(o, stream, nullptr, nullptr, nullptr);
+		if (rc) {
+			return rc;
+		}
+	}
+	uint64_t capacity = 1024;
+	while (capacity < 2 * max_groups) {
+		capacity <<= 1;
+	}
+	HashAggTable t;
+	memset(&t, 0, sizeof(t));
+	t.mask = capacity - 1;
+	t.max_groups = max_groups;
+	// one allocation: state, nulls, counters, keys, cells, and the compacted outputs behind them
+	const size_t b_state = capacity * 4, b_nulls = capacity * 4, b_cnt = 64, b_keys = capacity * n_cols * 8,
+	             b_cells = capacity * n_aggs * sizeof(GroupCell), b_okeys = max_groups * n_cols * 8, b_onulls = max_groups * 4,
+	             b_ocells = max_groups * n_aggs * sizeof(GroupCell);
+	uint8_t *base = nullptr;
+	HIPCHK(ctx, hipMalloc((void **)&base, b_state + b_nulls + b_cnt + b_keys + b_cells + b_okeys + b_onulls + b_ocells));
+	uint8_t *at = base;
+	t.state = (uint32_t *)at;
+	at += b_state;
+	t.nulls = (uint32_t *)at;
+	at += b_nulls;
+	unsigned long long *cnt = (unsigned long long *)at; // [0] groups, [1] overflow, [2] compaction cursor
+	at += b_cnt;
+	t.n_groups = cnt;
+	t.overflow = cnt + 1;
+	t.keys = (long long *)at;
+	at += b_keys;
+	t.cells = (GroupCell *)at;
+	at += b_cells;
+	long long *okeys = (long long *)at;
+	at += b_okeys;
+	uint32_t *onulls = (uint32_t *)at;
+	at += b_onulls;
+	GroupCell *ocells = (GroupCell *)at;
+	hipError_t e = hipMemsetAsync(base, 0, b_state + b_nulls + b_cnt, st);
+	unsigned long long h_cnt[3] = {0, 0, 0};
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(polr_hash_agg_init_kernel, dim3(256), dim3(256), 0, st, t, n_aggs);
+		if (o->n_chunks) {
+			hipLaunchKernelGGL(polr_hash_agg_kernel, dim3(std::min<uint32_t>(o->n_chunks, 2048u)), dim3(256), 0, st, o->dev, o->n_chunks,
+			                   gs, as, t);
+		}
+		hipLaunchKernelGGL(polr_hash_agg_compact_kernel, dim3(256), dim3(256), 0, st, t, n_cols, n_aggs, okeys, onulls, ocells, cnt + 2,
+		                   max_groups);
+		e = hipMemcpyAsync(h_cnt, cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st);
+		e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+	}
+	std::vector<GroupCell> hcells;
+	if (e == hipSuccess && !h_cnt[1] && h_cnt[0] <= max_groups && h_cnt[0]) {
+		const uint64_t g = h_cnt[0];
+		hcells.resize(g * n_aggs);
+		e = hipMemcpy(group_keys, okeys, g * n_cols * 8, hipMemcpyDeviceToHost);
+		e = e == hipSuccess ? hipMemcpy(group_nulls, onulls, g * 4, hipMemcpyDeviceToHost) : e;
+		e = e == hipSuccess ? hipMemcpy(hcells.data(), ocells, g * n_aggs * sizeof(GroupCell), hipMemcpyDeviceToHost) : e;
+	}
+	hipFree(base);
+	if (e != hipSuccess) {
+		POLR_FAIL(ctx, POLR_E_HIP, "hash aggregate failed: %s", hipGetErrorString(e));
+	}
+	*n_groups = h_cnt[0];
+	if (h_cnt[1] || h_cnt[0] > max_groups) {
+		POLR_FAIL(ctx, POLR_E_OVERFLOW, "the result has %llu groups or more, the caller made room for %llu",
+		          (unsigned long long)h_cnt[0], (unsigned long long)max_groups);
+	}
+	for (uint64_t g = 0; g < h_cnt[0]; g++) {
+		for (uint32_t a = 0; a < n_aggs; a++) {
+			cell_to_value(hcells[g * n_aggs + a], specs[a].fn, results[g * n_aggs + a]);
+		}
+	}
+	return POLR_OK;
+}
+
 // ---- the GROUP BY sink fused into an emitting flat pipeline (FusedSink, polr_device.h; polr_flat_device.h) -------------
 static_assert(POLR_AGG_COUNT_STAR == POLR_DEV_AGG_COUNT_STAR && POLR_AGG_COUNT == POLR_DEV_AGG_COUNT &&
                   POLR_AGG_SUM == POLR_DEV_AGG_SUM,

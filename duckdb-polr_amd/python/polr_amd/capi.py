@@ -36,7 +36,7 @@ EXPORTS = [
     "polr_mpx_run_backpressure", "polr_pipeline_scan_filter_lip", "polr_comm_get_unique_id", "polr_comm_create", "polr_bcast_build", "polr_comm_bytes_broadcast", "polr_comm_destroy",
     "polr_ctx_set_pool_tuning", "polr_ctx_get_stream",
     "polr_ht_set_payload_heap", "polr_pipeline_set_probe_heap", "polr_out_aggregate_string", "polr_ht_set_key_flags",
-    "polr_out_fuse_grouped", "polr_out_fused_result",
+    "polr_out_fuse_grouped", "polr_out_fused_result", "polr_out_aggregate_hashed",
 ]
 
 
@@ -188,6 +188,7 @@ def load():
     L.polr_out_aggregate.argtypes = [vp, vp, vp, u32, vp]
     L.polr_out_aggregate_grouped.argtypes = [vp, vp, vp, u32, vp, u32, vp, C.c_uint64, vp]
     L.polr_out_fuse_grouped.argtypes = [vp, vp, u32, vp, u32]
+    L.polr_out_aggregate_hashed.argtypes = [vp, vp, vp, u32, vp, u32, C.c_uint64, vp, vp, vp, vp]
     L.polr_out_fused_result.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.polr_mpx_run_resident.argtypes = [vp, vp, vp, vp, u32, vp, u32]
     L.polr_mpx_run_resident_morsels.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, u32, vp, u32]
@@ -575,6 +576,29 @@ class Output:
                  for a in range(na)] for g in range(n_groups)]
         counts = [[res[g * na + a].count for a in range(na)] for g in range(n_groups)]
         return vals, counts, dropped.value
+
+    def aggregate_hashed(self, cols, specs, max_groups, stream=None):
+        """polr_out_aggregate_hashed: GROUP BY over group columns of any integer domain.  cols = [(src_join, src_col)],
+        specs as in aggregate() -> {group key tuple (None = NULL): [value per aggregate (python int / None)]}"""
+        nk, na = len(cols), len(specs)
+        ka = (GroupKey * nk)()
+        for i, (sj, sc) in enumerate(cols):
+            ka[i].src_join, ka[i].src_col = sj, sc
+        sa = (AggSpec * na)()
+        for i, (fn, sj, sc) in enumerate(specs):
+            sa[i].fn, sa[i].src_join, sa[i].src_col = AGG[fn] if isinstance(fn, str) else fn, sj, sc
+        keys = np.zeros((max_groups, nk), dtype=np.int64)
+        nulls = np.zeros((max_groups,), dtype=np.uint32)
+        res = (AggValue * (max_groups * na))()
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.L.polr_out_aggregate_hashed(self.h, stream, ka, nk, sa, na, max_groups, keys.ctypes.data,
+                                                            nulls.ctypes.data, res, C.byref(n)))
+        out = {}
+        for g in range(n.value):
+            key = tuple(None if (nulls[g] >> c) & 1 else int(keys[g, c]) for c in range(nk))
+            out[key] = [None if res[g * na + a].is_null else (res[g * na + a].hi << 64) + (res[g * na + a].lo & 0xFFFFFFFFFFFFFFFF)
+                        for a in range(na)]
+        return out
 
     def fuse_grouped(self, keys, specs):
         """polr_out_fuse_grouped: fold the join result into group cells inside the run (flat pipelines of perfect tables;

@@ -354,6 +354,15 @@ typedef struct polr_group_key {
 int polr_out_aggregate_grouped(polr_out *o, void *stream, const polr_group_key *keys, uint32_t n_keys,
                                const polr_agg_spec *specs, uint32_t n_aggs, polr_agg_value *results,
                                uint64_t n_groups, uint64_t *n_dropped);
+/* The general GROUP BY sink -- group columns of ANY integer domain (what the reference plans as PhysicalHashAggregate,
+ * src/execution/operator/aggregate/physical_hash_aggregate.cpp, when the columns' statistics do not allow the perfect-hash
+ * form): a hash table of groups on the device, NULL a group value of its own (group_nulls: bit c = column c is NULL; its
+ * group_keys entry is then 0).  cols: src_join / src_col of polr_group_key (min_value, n_values ignored).  The groups come
+ * back in no particular order: group_keys[g * n_cols + c], results[g * n_aggs + a], *n_groups of them; POLR_E_OVERFLOW
+ * (with *n_groups = what was found until then) when there are more than max_groups. */
+int polr_out_aggregate_hashed(polr_out *o, void *stream, const polr_group_key *cols, uint32_t n_cols,
+                              const polr_agg_spec *specs, uint32_t n_aggs, uint64_t max_groups, int64_t *group_keys,
+                              uint32_t *group_nulls, polr_agg_value *results, uint64_t *n_groups);
 /* The same GROUP BY FUSED into the run (SSB-skew Q4.1 as shipped: benchmark/ssb-skew/queries/q4-1.sql): an output object
  * with a fused sink makes the pipeline's LAST join fold every surviving tuple into the group cells instead of writing its
  * row ids -- nothing of the join result is written or read back.  For FLAT pipelines whose joins are all perfect tables

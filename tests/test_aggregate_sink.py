@@ -449,3 +449,66 @@ def test_string_min_max_over_inline_and_heap_cells(gpu_ctx):
         out.aggregate_string("min", -1, 0)  # not a VARCHAR column
     pipe.close()
     ht.close()
+
+
+@pytest.mark.gpu
+def test_general_hash_aggregate(gpu_ctx):
+    """GROUP BY over group columns of any domain (PhysicalHashAggregate): a hash table of groups on the device.  Group
+    columns from the probe table and from two build sides, one with NULLs (NULL is a group of its own), wide and negative
+    key values, thousands of groups and a handful; COUNT(*), COUNT, SUM, MIN, MAX against a numpy GROUP BY over the oracle's
+    join result; more groups than the caller made room for -> POLR_E_OVERFLOW"""
+    from polr_amd import capi
+    wl = workloads.star_skew(n_fact=150_000, with_nulls=True)  # (NULL keys and NULL payload cells)
+    k = len(wl["joins"])
+    paths = workloads.default_paths(k, "each_last_once")
+    pcols, pvalid, ojoins = common.oracle_joins(wl)
+    n = len(pcols[0])
+    ref = orc.run_pipeline(pcols, ojoins, paths[:1], routing="default_path", collect_output=True, probe_valid=pvalid)
+    rows = ref["out_rows"]
+    joins = capi.build_joins(gpu_ctx, wl)
+    pipe = capi.Pipeline(gpu_ctx, pcols, n, joins, paths, probe_valid=pvalid)
+    out = capi.Output(pipe, 1024, len(rows) // 1024 + 4096)
+    mpx = capi.DeviceMultiplexer(pipe, "default_path")
+    mpx.run_resident(0, (n + 1023) // 1024, out=out)
+    mpx.finish()
+    assert out.stats()[0] == len(rows)
+    names = list(wl["probe"]["cols"].keys())
+    j0 = wl["joins"][0]
+    p0 = list(j0["payload"].keys())
+    # group columns: probe column 1 (a key column: thousands of values), payload 0 of join 0 (with its NULLs, if any)
+    gcols = [(-1, 1), (0, 0)]
+    specs = [("count_star", -1, 0), ("sum", -1, 0), ("min", -1, 0), ("max", 0, 0), ("count", 0, 0)]
+    got = out.aggregate_hashed(gcols, specs, 1 << 16)
+
+    def col(sj, sc):
+        if sj < 0:
+            return orc.materialize_column(rows, k, -1, pcols[sc], pvalid[sc] if pvalid else None)
+        arr = list(wl["joins"][sj]["payload"].values())[sc]
+        val = wl["joins"][sj].get("payload_valid", {}).get(list(wl["joins"][sj]["payload"].keys())[sc])
+        return orc.materialize_column(rows, k, sj, arr, val)
+
+    g0, v0 = col(*gcols[0])
+    g1, v1 = col(*gcols[1])
+    a0, av0 = col(-1, 0)
+    a1, av1 = col(0, 0)
+    want = {}
+    for i in range(len(rows)):
+        key = (None if v0 is not None and not v0[i] else int(g0[i]), None if v1 is not None and not v1[i] else int(g1[i]))
+        w = want.setdefault(key, [0, 0, None, None, 0])
+        w[0] += 1
+        w[1] += int(a0[i])
+        w[2] = int(a0[i]) if w[2] is None else min(w[2], int(a0[i]))
+        if av1 is None or av1[i]:
+            w[3] = int(a1[i]) if w[3] is None else max(w[3], int(a1[i]))
+            w[4] += 1
+    assert len(got) == len(want) and len(want) > 1000
+    for key, w in want.items():
+        assert got[key] == w, key
+    # one group column
+    one = out.aggregate_hashed([(0, 0)], [("count_star", -1, 0)], 1 << 16)
+    assert sum(v[0] for v in one.values()) == len(rows) and set(one) == {(k2[1],) for k2 in want}
+    with pytest.raises(capi.PolrError) as e:
+        out.aggregate_hashed(gcols, specs, 16)
+    assert e.value.code == capi.E_OVERFLOW
+    mpx.close()
+    pipe.close()
