@@ -957,6 +957,16 @@ def run_job_full(args, env, steps, warmup, with_cpu):
                     "algorithmic_bytes_per_step": round(alg), "kernel_ms_per_step": round(kernel_ms / steps, 4),
                     "launches_per_step": launches / steps,
                     "note": "rank 0's pipelines; algorithmic bytes per SURVEY.md 8(d) summed over them"}
+            sig = {"workload": "job_full", "scale": float(scale), "routing": args.routing, "join_enumerator": "each_last_once",
+                   "max_join_orders": 8, "executors_per_gpu": int(E), "n_gpus": int(world)}
+            roof["pmc_signature"] = sig
+            pmc, pmc_file = find_pmc_summary(sig)
+            if pmc:
+                # REPLAYED: the mean HBM bytes per pool-kernel dispatch of the same command's separate --pmc passes x the
+                # launches of a pass
+                roof["traffic"] = int(pmc["traffic_bytes_per_launch_corrected"] * (launches / steps))
+                roof["traffic_source"] = "replayed from profiles/" + pmc_file + " (mean per dispatch x launches per pass)"
+                roof["traffic_note"] = pmc["traffic_note"]
         cpu = None
         if with_cpu:
             try:

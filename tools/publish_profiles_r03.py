@@ -40,6 +40,8 @@ def signature(line):
            "join_enumerator": cfg.get("join_enumerator"), "max_join_orders": cfg.get("max_join_orders")}
     if "executors_per_gpu" in cfg:
         sig["executors_per_gpu"] = cfg["executors_per_gpu"]
+    elif "executors_per_pipeline" in cfg:  # (job_full)
+        sig["executors_per_gpu"] = cfg["executors_per_pipeline"]
     sig["n_gpus"] = line.get("n_gpus", 1)
     return sig
 
