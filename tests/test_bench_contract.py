@@ -1,14 +1,18 @@
-"""The driver's bench contract, checked on the line this repository last committed (profiles/r02_bench_default.json =
-stdout of `python bench.py` on the GPU box): one JSON object with the contract's keys, BASELINE.json's metric and unit,
-and the two objects this tier adds (`roofline`, `cpu_baseline`)."""
+"""The driver's bench contract, checked on the lines this repository committed (profiles/r02_bench_default.json,
+profiles/r03_bench_default.json = stdout of `python bench.py` on the GPU box): one JSON object with the contract's keys,
+BASELINE.json's metric and unit, and the two objects this tier adds (`roofline`, `cpu_baseline`)."""
 import json
 import os
 
 import common
 
 
-def test_committed_bench_line_has_the_contract_shape():
-    path = os.path.join(common.ROOT, "profiles", "r02_bench_default.json")
+import pytest
+
+
+@pytest.mark.parametrize("line", ["r02_bench_default.json", "r03_bench_default.json"])
+def test_committed_bench_line_has_the_contract_shape(line):
+    path = os.path.join(common.ROOT, "profiles", line)
     lines = [l for l in open(path).read().splitlines() if l.strip()]
     assert len(lines) == 1  # ONE JSON line
     d = json.loads(lines[0])
@@ -36,7 +40,33 @@ def test_committed_bench_line_has_the_contract_shape():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["count_star_matches_reference"] is True
     for sub in d.get("sub_records", []):
-        assert {"value", "ms_per_step", "roofline", "config"} <= set(sub)
+        assert {"value", "ms_per_step", "config"} <= set(sub)
+    if line.startswith("r03"):
+        # round 3: the traffic of the headline AND of the JOB sub-records is replayed from committed PMC summaries whose
+        # signature is the run's; the sub-record with the shipped GROUP BY carries the reference's figure on the same SQL
+        assert r["traffic"] and r["pmc_signature"] == json.load(open(os.path.join(
+            common.ROOT, "profiles", r["traffic_source"].split("profiles/")[1])))["workload_signature"]
+        subs = {sub["config"]["workload"].split(" ")[0].rstrip(":"): sub for sub in d["sub_records"]}
+        for name in ("job_q18", "job_light_01"):
+            rs = subs[name]["roofline"]
+            assert rs["traffic"] and "replayed" in rs["traffic_source"] and rs["traffic"] >= rs["algorithmic_bytes_per_step"]
+            assert subs[name]["cpu_baseline"]["kind"] == "reference"
+        shipped = subs["ssb_skew_q41"]
+        assert "as shipped" in shipped["config"]["workload"] and shipped["count_star"] == d["count_star"]
+        assert shipped["cpu_baseline"]["kind"] == "reference" and shipped["cpu_baseline"]["value"] > 0
+
+
+def test_committed_pmc_summaries_match_the_commands_bench_runs():
+    """the signatures bench.py looks a replayed `roofline.traffic` up by: one committed summary for each of the default
+    line's records and for the 113-pipeline pass"""
+    import glob
+    sigs = [json.load(open(f))["workload_signature"] for f in glob.glob(os.path.join(common.ROOT, "profiles", "r03_*_pmc_summary.json"))]
+    base = {"routing": "adaptive_reinit", "n_gpus": 1}
+    for want in ({"workload": "ssb_skew_q41", "scale": 100.0, "join_enumerator": "sample", "max_join_orders": 3, "executors_per_gpu": 384},
+                 {"workload": "job_q18", "scale": 1.0, "join_enumerator": "each_last_once", "max_join_orders": 8, "executors_per_gpu": 32},
+                 {"workload": "job_light_01", "scale": 1.0, "join_enumerator": "each_last_once", "max_join_orders": 8, "executors_per_gpu": 32},
+                 {"workload": "job_full", "scale": 1.0, "join_enumerator": "each_last_once", "max_join_orders": 8, "executors_per_gpu": 16}):
+        assert dict(base, **want) in sigs, want
 
 
 _RANK_SCRIPT = r"""
